@@ -1,0 +1,161 @@
+"""Host-side surface of the direct-summation engine: compute_forces() / step() / energy().
+
+These are the in-process functions SURVEY.md §8(a) rows ⊕1-⊕3 define for the path that the reference only
+reaches by spawning CONCEPT with `gravity: 'pp'` (SnapVsPK/Ucertain.py:89-97, Different_Sizes/Giant.param:66-68).
+Signatures and semantics are the same as the CPU oracle's (oracle/nbody_oracle.py) so parity tests call both
+with identical arguments — but everything here runs on the MI355X through the C-ABI (include/nbody_amd.h);
+there is no CPU path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .state import State
+
+_DT = {np.dtype(np.float32): _lib.NB_F32, np.dtype(np.float64): _lib.NB_F64}
+
+
+def _code(dtype) -> int:
+    try:
+        return _DT[np.dtype(dtype)]
+    except KeyError:
+        raise TypeError(f"dtype must be float32 or float64, got {dtype}") from None
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One nb_ctx: `n` particles resident on one MI355X, state kept as SoA in HBM between calls."""
+
+    def __init__(self, n: int, dtype=np.float32, device: int = 0):
+        self._lib = _lib.load()
+        self.n, self.dtype, self.device = int(n), np.dtype(dtype), int(device)
+        self._ctx = C.c_void_p()
+        rc = self._lib.nb_create(C.byref(self._ctx), self.n, _code(self.dtype), self.device)
+        if rc != _lib.NB_OK:
+            self._ctx = C.c_void_p()
+            _lib.check(None, rc, "nb_create")
+
+    # -- lifetime -------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.nb_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._ctx
+
+    def set_stream(self, hip_stream: int) -> None:
+        _lib.check(self._ctx, self._lib.nb_set_stream(self._ctx, C.c_void_p(hip_stream)), "nb_set_stream")
+
+    def synchronize(self) -> None:
+        _lib.check(self._ctx, self._lib.nb_synchronize(self._ctx), "nb_synchronize")
+
+    # -- state ----------------------------------------------------------------------------------
+    def _soa(self, a: np.ndarray, name: str):
+        a = np.asarray(a)
+        if a.shape != (self.n, 3):
+            raise ValueError(f"{name} must have shape ({self.n}, 3), got {a.shape}")
+        t = np.ascontiguousarray(a.T, dtype=self.dtype)  # (3, N): x, y, z rows contiguous
+        return t
+
+    def set_state(self, state: State) -> None:
+        p = self._soa(state.pos, "pos")
+        v = self._soa(state.vel, "vel")
+        m = np.ascontiguousarray(state.mass, dtype=self.dtype)
+        if m.shape != (self.n,):
+            raise ValueError(f"mass must have shape ({self.n},), got {m.shape}")
+        rc = self._lib.nb_set_state(self._ctx, _ptr(p[0]), _ptr(p[1]), _ptr(p[2]), _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), _ptr(m))
+        _lib.check(self._ctx, rc, "nb_set_state")
+
+    def get_state(self) -> State:
+        p = np.empty((3, self.n), self.dtype)
+        v = np.empty((3, self.n), self.dtype)
+        m = np.empty(self.n, self.dtype)
+        rc = self._lib.nb_get_state(self._ctx, _ptr(p[0]), _ptr(p[1]), _ptr(p[2]), _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), _ptr(m))
+        _lib.check(self._ctx, rc, "nb_get_state")
+        return State(np.ascontiguousarray(p.T), np.ascontiguousarray(v.T), m)
+
+    # -- compute --------------------------------------------------------------------------------
+    def accel(self, eps: float, G: float = 1.0, fetch: bool = True) -> Optional[np.ndarray]:
+        """a(x) of the resident particles; (N,3) array, or None with fetch=False (device-side refresh only)."""
+        if not fetch:
+            _lib.check(self._ctx, self._lib.nb_accel(self._ctx, eps, G, None, None, None), "nb_accel")
+            return None
+        a = np.empty((3, self.n), self.dtype)
+        _lib.check(self._ctx, self._lib.nb_accel(self._ctx, eps, G, _ptr(a[0]), _ptr(a[1]), _ptr(a[2])), "nb_accel")
+        return np.ascontiguousarray(a.T)
+
+    def cached_acc(self) -> np.ndarray:
+        """The acceleration left on the device by the last accel()/step() — no recomputation."""
+        a = np.empty((3, self.n), self.dtype)
+        _lib.check(self._ctx, self._lib.nb_get_acc(self._ctx, _ptr(a[0]), _ptr(a[1]), _ptr(a[2])), "nb_get_acc")
+        return np.ascontiguousarray(a.T)
+
+    def step(self, dt: float, nsteps: int = 1, eps: float = 0.0, G: float = 1.0) -> None:
+        _lib.check(self._ctx, self._lib.nb_step(self._ctx, dt, int(nsteps), eps, G), "nb_step")
+
+    def energy(self, eps: float, G: float = 1.0) -> Tuple[float, float]:
+        k, u = C.c_double(), C.c_double()
+        _lib.check(self._ctx, self._lib.nb_energy(self._ctx, eps, G, C.byref(k), C.byref(u)), "nb_energy")
+        return k.value, u.value
+
+
+def _infer_dtype(a, dtype):
+    if dtype is not None:
+        return np.dtype(dtype)
+    d = np.asarray(a).dtype
+    return d if d in _DT else np.dtype(np.float64)
+
+
+def compute_forces(pos, mass, eps: float, G: float = 1.0, dtype=None, device: int = 0) -> np.ndarray:
+    """Softened all-pairs acceleration a_i = G sum_j m_j (r_j-r_i)/(r_ij^2+eps^2)^{3/2} on the GPU.
+    `dtype` defaults to the dtype of `pos` (float32 -> fp32 kernel, anything else -> fp64 kernel)."""
+    pos = np.asarray(pos)
+    dt = _infer_dtype(pos, dtype)
+    n = pos.shape[0]
+    if n == 0:
+        return np.zeros((0, 3), dt)
+    with Engine(n, dt, device) as e:
+        e.set_state(State(pos, np.zeros_like(pos), np.asarray(mass)))
+        return e.accel(eps, G)
+
+
+def step(state: State, dt: float, nsteps: int = 1, eps: float = 0.0, G: float = 1.0, dtype=None,
+         device: int = 0) -> State:
+    """`nsteps` kick-drift-kick steps on the GPU, written back into `state` (pos, vel, acc); returns it."""
+    d = _infer_dtype(state.pos, dtype)
+    with Engine(state.n, d, device) as e:
+        e.set_state(state)
+        e.step(dt, nsteps, eps, G)
+        out = e.get_state()
+        acc = e.cached_acc() if nsteps > 0 else None
+    state.pos, state.vel = out.pos.astype(state.pos.dtype, copy=False), out.vel.astype(state.vel.dtype, copy=False)
+    state.acc = acc
+    return state
+
+
+def energy(state: State, eps: float, G: float = 1.0, dtype=None, device: int = 0) -> Tuple[float, float]:
+    d = _infer_dtype(state.pos, dtype)
+    with Engine(state.n, d, device) as e:
+        e.set_state(state)
+        return e.energy(eps, G)

@@ -1,0 +1,203 @@
+// fp64 softened all-pairs acceleration for gfx950 (MI355X) — SURVEY.md §8(a) row ⊕1, configs[3].
+//
+// Same structure as accel_f32.hip (SoA sinks in VGPRs, sources re-packed to (x,y,z,m) in a
+// double-buffered LDS tile read with wave-uniform addresses, split-source slabs for small N), bounded by
+// the vector-FP64 rate (v_fma_f64 = half the fp32 rate). There is no packed fp64 math and no fast fp64
+// rsqrt, so 1/sqrt(r^2) is a hardware seed refined by ONE Halley step (cubic convergence):
+//     y0 = v_rsq_f64(r2)                       (~2^-26 relative)  [RSQ_MODE 0]
+//     y0 = (double) v_rsq_f32((float) r2)      (~2^-23 relative)  [RSQ_MODE 1; r2 must fit fp32 range]
+//     h  = 1 - r2*y0^2 ;  y = y0 * (1 + h/2 + 3h^2/8)            -> relative error ~ h^3 < 1e-20
+// Per interaction: 3 add, 3 fma, seed, 5 (Halley), 3 mul, 3 fma = 17 fp64 VALU + seed.
+#include "nb_common.h"
+#include "../../include/nbody_amd.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int BLOCK = 256;
+struct d4 { double x, y, z, w; };
+
+template <int RSQ_MODE>
+__device__ inline double rsqrt_f64(double r2) {
+  double y;
+  if (RSQ_MODE == 0) y = __builtin_amdgcn_rsq(r2);
+  else y = (double)__builtin_amdgcn_rsqf((float)r2);
+  const double h = fma(-r2 * y, y, 1.0);
+  return y * fma(h, fma(0.375, h, 0.5), 1.0);
+}
+
+template <int KS, int TILE, bool GUARD, int RSQ_MODE>
+__global__ void __launch_bounds__(BLOCK)
+accel_f64_kernel(const double* __restrict__ xi, const double* __restrict__ yi, const double* __restrict__ zi,
+                 int n_snk,
+                 const double* __restrict__ xs, const double* __restrict__ ys, const double* __restrict__ zs,
+                 const double* __restrict__ ms, int n_src, int src_per_split,
+                 double eps2, double G,
+                 double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az,
+                 double* __restrict__ part, int accumulate) {
+  static_assert(TILE % BLOCK == 0, "tile must be a multiple of the block size");
+  constexpr int LPT = TILE / BLOCK;
+  __shared__ d4 tile[2][TILE];
+
+  const int tid = threadIdx.x;
+  const int i0 = blockIdx.x * (BLOCK * KS) + tid;
+
+  double px[KS], py[KS], pz[KS], fx[KS], fy[KS], fz[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    int i = i0 + k * BLOCK;
+    i = i < n_snk ? i : n_snk - 1;
+    px[k] = xi[i]; py[k] = yi[i]; pz[k] = zi[i];
+    fx[k] = 0.0; fy[k] = 0.0; fz[k] = 0.0;
+  }
+  double e2 = eps2;
+  asm volatile("" : "+v"(e2));  // keep eps^2 in VGPRs (SGPR operands halve the VALU issue rate)
+
+  const int jbeg = blockIdx.y * src_per_split;
+  const int jend = min(n_src, jbeg + src_per_split);
+  const int ntiles = (jend - jbeg + TILE - 1) / TILE;
+
+  d4 stage[LPT];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int l = 0; l < LPT; ++l) {
+      const int j = jbeg + t * TILE + l * BLOCK + tid;
+      const bool ok = j < jend;
+      const int jc = ok ? j : jend - 1;
+      stage[l] = d4{xs[jc], ys[jc], zs[jc], ok ? ms[jc] : 0.0};
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int l = 0; l < LPT; ++l) tile[buf][l * BLOCK + tid] = stage[l];
+  };
+
+  if (ntiles > 0) { fetch(0); commit(0); }
+#pragma unroll
+  for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(px[k]), "+v"(py[k]), "+v"(pz[k]));
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) fetch(t + 1);
+#pragma unroll 4
+    for (int j = 0; j < TILE; ++j) {
+      const d4 s = tile[buf][j];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        const double dx = s.x - px[k];
+        const double dy = s.y - py[k];
+        const double dz = s.z - pz[k];
+        const double r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, e2)));
+        double rinv = rsqrt_f64<RSQ_MODE>(r2);
+        if (GUARD) rinv = r2 > e2 ? rinv : 0.0;
+        const double rinv2 = rinv * rinv;
+        const double mr = s.w * rinv;
+        const double f = mr * rinv2;
+        fx[k] = fma(f, dx, fx[k]);
+        fy[k] = fma(f, dy, fy[k]);
+        fz[k] = fma(f, dz, fz[k]);
+      }
+    }
+    if (t + 1 < ntiles) commit(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (gridDim.y == 1) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int i = i0 + k * BLOCK;
+      if (i < n_snk) {
+        double ox = G * fx[k], oy = G * fy[k], oz = G * fz[k];
+        if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
+        ax[i] = ox; ay[i] = oy; az[i] = oz;
+      }
+    }
+  } else {
+    double* p = part + (size_t)blockIdx.y * 3 * (size_t)n_snk;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int i = i0 + k * BLOCK;
+      if (i < n_snk) { p[i] = fx[k]; p[(size_t)n_snk + i] = fy[k]; p[2 * (size_t)n_snk + i] = fz[k]; }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+accel_reduce_f64_kernel(const double* __restrict__ part, int nsplit, int n_snk, double G,
+                        double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_snk) return;
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    const double* p = part + (size_t)s * 3 * (size_t)n_snk;
+    sx += p[i]; sy += p[(size_t)n_snk + i]; sz += p[2 * (size_t)n_snk + i];
+  }
+  double ox = G * sx, oy = G * sy, oz = G * sz;
+  if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
+  ax[i] = ox; ay[i] = oy; az[i] = oz;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+template <int KS, int TILE, int RSQ_MODE>
+void launch_variant(bool guard, dim3 grid, hipStream_t st, const double* xi, const double* yi, const double* zi,
+                    int n_snk, const double* xs, const double* ys, const double* zs, const double* ms, int n_src,
+                    int sps, double eps2, double G, double* ax, double* ay, double* az, double* part, int accumulate) {
+  if (guard)
+    accel_f64_kernel<KS, TILE, true, RSQ_MODE><<<grid, BLOCK, 0, st>>>(xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps,
+                                                                      eps2, G, ax, ay, az, part, accumulate);
+  else
+    accel_f64_kernel<KS, TILE, false, RSQ_MODE><<<grid, BLOCK, 0, st>>>(xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps,
+                                                                       eps2, G, ax, ay, az, part, accumulate);
+}
+
+}  // namespace
+
+int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const double* zi, int64_t n_snk,
+                        const double* xs, const double* ys, const double* zs, const double* ms, int64_t n_src,
+                        double eps2, double G, double* ax, double* ay, double* az, int accumulate) {
+  if (n_snk <= 0) return NB_OK;
+  if (n_snk >= (1ll << 31) || n_src >= (1ll << 31)) return nb_fail(c, NB_ERR_ARG, "n must be < 2^31");
+  constexpr int TILE = 256;
+  int ks = env_int("NB_F64_KS", 0);
+  if (ks != 1 && ks != 2 && ks != 4) ks = n_snk >= 128 * 1024 ? 2 : 1;
+  const int rsq_mode = env_int("NB_F64_RSQ", 0);
+  const int spb = BLOCK * ks;
+  const int nblk = (int)((n_snk + spb - 1) / spb);
+  int nsplit = env_int("NB_F64_SPLIT", 0);
+  const int ntiles_total = (int)((n_src + TILE - 1) / TILE);
+  if (nsplit <= 0) nsplit = nblk >= 2048 ? 1 : (2048 + nblk - 1) / nblk;
+  if (nsplit > ntiles_total) nsplit = ntiles_total > 0 ? ntiles_total : 1;
+  if (nsplit > 65535) nsplit = 65535;
+  int tps = (ntiles_total + nsplit - 1) / nsplit;
+  if (tps < 1) tps = 1;
+  nsplit = ntiles_total > 0 ? (ntiles_total + tps - 1) / tps : 1;
+  const long long sps_ll = (long long)tps * TILE;
+  const int sps = sps_ll > 0x7fffffff ? 0x7fffffff : (int)sps_ll;
+
+  double* part = nullptr;
+  if (nsplit > 1) {
+    int rc = nb_ensure_work(c, (size_t)nsplit * 3 * (size_t)n_snk * sizeof(double));
+    if (rc) return rc;
+    part = reinterpret_cast<double*>(c->work);
+  }
+  const bool guard = !(eps2 > 0.0);
+  dim3 grid(nblk, nsplit);
+#define NB_GO(K, M) launch_variant<K, TILE, M>(guard, grid, c->stream, xi, yi, zi, (int)n_snk, xs, ys, zs, ms, (int)n_src, sps, eps2, G, ax, ay, az, part, accumulate)
+  if (rsq_mode == 1) {
+    if (ks == 1) NB_GO(1, 1); else if (ks == 4) NB_GO(4, 1); else NB_GO(2, 1);
+  } else {
+    if (ks == 1) NB_GO(1, 0); else if (ks == 4) NB_GO(4, 0); else NB_GO(2, 0);
+  }
+#undef NB_GO
+  NB_HIP(c, hipGetLastError());
+  if (nsplit > 1) {
+    accel_reduce_f64_kernel<<<(int)((n_snk + 255) / 256), 256, 0, c->stream>>>(part, nsplit, (int)n_snk, G, ax, ay, az, accumulate);
+    NB_HIP(c, hipGetLastError());
+  }
+  return NB_OK;
+}

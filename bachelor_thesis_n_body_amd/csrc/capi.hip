@@ -1,0 +1,303 @@
+// C-ABI of libnbody_amd.so (declared in include/nbody_amd.h): context lifetime, host<->device state
+// transfer, and the compute_forces()/step()/energy() drivers that string the HIP kernels together on one
+// stream with no host round trip inside nb_step().
+#include "nb_common.h"
+#include "../../include/nbody_amd.h"
+#include <cstring>
+#include <new>
+
+static thread_local std::string g_create_err;
+
+int nb_fail(nb_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg; else g_create_err = msg;
+  return code;
+}
+
+int nb_ensure_work(nb_ctx* c, size_t bytes) {
+  if (bytes <= c->work_bytes) return NB_OK;
+  // earlier kernels on the stream may still read the old buffer
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->work) { NB_HIP(c, hipFree(c->work)); c->work = nullptr; c->work_bytes = 0; }
+  size_t want = bytes + bytes / 4;
+  NB_HIP(c, hipMalloc(&c->work, want));
+  c->work_bytes = want;
+  return NB_OK;
+}
+
+static inline size_t esize(int dtype) { return dtype == NB_F64 ? 8 : 4; }
+
+static int use_device(nb_ctx* c) {
+  NB_HIP(c, hipSetDevice(c->device));
+  return NB_OK;
+}
+
+extern "C" {
+
+int nb_version(void) { return 100; }
+
+int nb_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { g_create_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); return NB_ERR_HIP; }
+  return n;
+}
+
+const char* nb_last_error(const nb_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int nb_create(nb_ctx** out, int64_t n, int dtype, int device) {
+  if (!out) return nb_fail(nullptr, NB_ERR_ARG, "nb_create: out is NULL");
+  *out = nullptr;
+  if (n <= 0) return nb_fail(nullptr, NB_ERR_ARG, "nb_create: n must be > 0");
+  if (n >= (1ll << 31)) return nb_fail(nullptr, NB_ERR_ARG, "nb_create: n must be < 2^31");
+  if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(nullptr, NB_ERR_ARG, "nb_create: dtype must be NB_F32 or NB_F64");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return nb_fail(nullptr, NB_ERR_NODEVICE, std::string("nb_create: no HIP device visible (") + hipGetErrorString(e) + ")");
+  if (device < 0 || device >= ndev) return nb_fail(nullptr, NB_ERR_NODEVICE, "nb_create: device index out of range");
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return nb_fail(nullptr, NB_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return nb_fail(nullptr, NB_ERR_NODEVICE, std::string("nb_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  nb_ctx* c = new (std::nothrow) nb_ctx();
+  if (!c) return nb_fail(nullptr, NB_ERR_ARG, "nb_create: out of host memory");
+  c->device = device; c->dtype = dtype; c->n = n;
+  auto bail = [&](const char* what, hipError_t err) {
+    std::string m = std::string(what) + ": " + hipGetErrorString(err);
+    if (c->state) (void)hipFree(c->state);
+    if (c->scal) (void)hipFree(c->scal);
+    if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return nb_fail(nullptr, NB_ERR_HIP, m);
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  c->own_stream = true;
+  if ((e = hipMalloc(&c->state, (size_t)10 * (size_t)n * esize(dtype))) != hipSuccess) return bail("hipMalloc(state)", e);
+  if ((e = hipMemset(c->state, 0, (size_t)10 * (size_t)n * esize(dtype))) != hipSuccess) return bail("hipMemset(state)", e);
+  if ((e = hipMalloc((void**)&c->scal, 8 * sizeof(double))) != hipSuccess) return bail("hipMalloc(scalars)", e);
+  *out = c;
+  return NB_OK;
+}
+
+int nb_destroy(nb_ctx* c) {
+  if (!c) return NB_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->state) (void)hipFree(c->state);
+  if (c->work) (void)hipFree(c->work);
+  if (c->scal) (void)hipFree(c->scal);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return NB_OK;
+}
+
+int nb_set_stream(nb_ctx* c, void* hip_stream) {
+  if (!c) return NB_ERR_ARG;
+  int rc = use_device(c); if (rc) return rc;
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  // the handle is used as given; NULL is HIP's default (null) stream, which is what torch's default stream is
+  if (c->own_stream) { NB_HIP(c, hipStreamDestroy(c->stream)); c->own_stream = false; }
+  c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return NB_OK;
+}
+
+int nb_synchronize(nb_ctx* c) {
+  if (!c) return NB_ERR_ARG;
+  int rc = use_device(c); if (rc) return rc;
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  return NB_OK;
+}
+
+int nb_set_state(nb_ctx* c, const void* x, const void* y, const void* z, const void* vx, const void* vy,
+                 const void* vz, const void* m) {
+  if (!c) return NB_ERR_ARG;
+  if (!x || !y || !z || !vx || !vy || !vz || !m) return nb_fail(c, NB_ERR_ARG, "nb_set_state: NULL array");
+  int rc = use_device(c); if (rc) return rc;
+  const size_t b = (size_t)c->n * esize(c->dtype);
+  char* base = reinterpret_cast<char*>(c->state);
+  const void* src[7] = {x, y, z, m, vx, vy, vz};  // device field order: x y z m vx vy vz ax ay az
+  for (int f = 0; f < 7; ++f) NB_HIP(c, hipMemcpyAsync(base + (size_t)f * b, src[f], b, hipMemcpyHostToDevice, c->stream));
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  c->acc_valid = false;
+  c->has_state = true;
+  return NB_OK;
+}
+
+int nb_get_state(nb_ctx* c, void* x, void* y, void* z, void* vx, void* vy, void* vz, void* m) {
+  if (!c) return NB_ERR_ARG;
+  if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_get_state: no state set");
+  int rc = use_device(c); if (rc) return rc;
+  const size_t b = (size_t)c->n * esize(c->dtype);
+  char* base = reinterpret_cast<char*>(c->state);
+  void* dst[7] = {x, y, z, m, vx, vy, vz};
+  for (int f = 0; f < 7; ++f)
+    if (dst[f]) NB_HIP(c, hipMemcpyAsync(dst[f], base + (size_t)f * b, b, hipMemcpyDeviceToHost, c->stream));
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  return NB_OK;
+}
+
+// a(x) of the context's own particles into the state's ax/ay/az fields
+static int refresh_acc(nb_ctx* c, double eps, double G) {
+  int rc;
+  if (c->dtype == NB_F32) {
+    float* s = reinterpret_cast<float*>(c->state);
+    const size_t n = (size_t)c->n;
+    rc = nb_launch_accel_f32(c, s, s + n, s + 2 * n, c->n, s, s + n, s + 2 * n, s + 3 * n, c->n,
+                             (float)(eps * eps), (float)G, s + 7 * n, s + 8 * n, s + 9 * n, 0);
+  } else {
+    double* s = reinterpret_cast<double*>(c->state);
+    const size_t n = (size_t)c->n;
+    rc = nb_launch_accel_f64(c, s, s + n, s + 2 * n, c->n, s, s + n, s + 2 * n, s + 3 * n, c->n, eps * eps, G,
+                             s + 7 * n, s + 8 * n, s + 9 * n, 0);
+  }
+  if (rc) return rc;
+  c->acc_valid = true; c->acc_eps = eps; c->acc_G = G;
+  return NB_OK;
+}
+
+int nb_accel(nb_ctx* c, double eps, double G, void* ax, void* ay, void* az) {
+  if (!c) return NB_ERR_ARG;
+  if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_accel: call nb_set_state first");
+  if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_accel: eps must be >= 0");
+  int rc = use_device(c); if (rc) return rc;
+  rc = refresh_acc(c, eps, G); if (rc) return rc;
+  const size_t b = (size_t)c->n * esize(c->dtype);
+  char* base = reinterpret_cast<char*>(c->state);
+  void* dst[3] = {ax, ay, az};
+  for (int f = 0; f < 3; ++f)
+    if (dst[f]) NB_HIP(c, hipMemcpyAsync(dst[f], base + (size_t)(7 + f) * b, b, hipMemcpyDeviceToHost, c->stream));
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  return NB_OK;
+}
+
+int nb_get_acc(nb_ctx* c, void* ax, void* ay, void* az) {
+  if (!c) return NB_ERR_ARG;
+  if (!c->has_state || !c->acc_valid) return nb_fail(c, NB_ERR_STATE, "nb_get_acc: no cached acceleration (call nb_accel or nb_step first)");
+  int rc = use_device(c); if (rc) return rc;
+  const size_t b = (size_t)c->n * esize(c->dtype);
+  char* base = reinterpret_cast<char*>(c->state);
+  void* dst[3] = {ax, ay, az};
+  for (int f = 0; f < 3; ++f)
+    if (dst[f]) NB_HIP(c, hipMemcpyAsync(dst[f], base + (size_t)(7 + f) * b, b, hipMemcpyDeviceToHost, c->stream));
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  return NB_OK;
+}
+
+int nb_step(nb_ctx* c, double dt, int64_t nsteps, double eps, double G) {
+  if (!c) return NB_ERR_ARG;
+  if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_step: call nb_set_state first");
+  if (nsteps < 0) return nb_fail(c, NB_ERR_ARG, "nb_step: nsteps must be >= 0");
+  if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_step: eps must be >= 0");
+  if (nsteps == 0) return NB_OK;
+  int rc = use_device(c); if (rc) return rc;
+  if (!c->acc_valid || c->acc_eps != eps || c->acc_G != G) { rc = refresh_acc(c, eps, G); if (rc) return rc; }
+  const size_t b = (size_t)c->n * esize(c->dtype);
+  char* s = reinterpret_cast<char*>(c->state);
+  void *x = s, *y = s + b, *z = s + 2 * b, *vx = s + 4 * b, *vy = s + 5 * b, *vz = s + 6 * b;
+  void *ax = s + 7 * b, *ay = s + 8 * b, *az = s + 9 * b;
+  const double h = 0.5 * dt;
+  for (int64_t k = 0; k < nsteps; ++k) {
+    // step k: [closing half-kick of step k-1, fused] opening half-kick, drift; force; (closing kick deferred)
+    rc = nb_launch_kick_drift(c, c->dtype, x, y, z, vx, vy, vz, ax, ay, az, c->n, k == 0 ? 0.0 : h, h, dt);
+    if (rc) return rc;
+    rc = refresh_acc(c, eps, G); if (rc) return rc;
+  }
+  rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, h); if (rc) return rc;
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  return NB_OK;
+}
+
+int nb_energy(nb_ctx* c, double eps, double G, double* kinetic, double* potential) {
+  if (!c) return NB_ERR_ARG;
+  if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_energy: call nb_set_state first");
+  if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_energy: eps must be >= 0");
+  int rc = use_device(c); if (rc) return rc;
+  const size_t b = (size_t)c->n * esize(c->dtype);
+  char* s = reinterpret_cast<char*>(c->state);
+  rc = nb_launch_kinetic(c, c->dtype, s + 4 * b, s + 5 * b, s + 6 * b, s + 3 * b, c->n, c->scal); if (rc) return rc;
+  if (c->dtype == NB_F32)
+    rc = nb_launch_potential_f32(c, (float*)s, (float*)(s + b), (float*)(s + 2 * b), (float*)(s + 3 * b), c->n, 0,
+                                 (float*)s, (float*)(s + b), (float*)(s + 2 * b), (float*)(s + 3 * b), c->n, 0,
+                                 (float)(eps * eps), c->scal + 1, 0);
+  else
+    rc = nb_launch_potential_f64(c, (double*)s, (double*)(s + b), (double*)(s + 2 * b), (double*)(s + 3 * b), c->n, 0,
+                                 (double*)s, (double*)(s + b), (double*)(s + 2 * b), (double*)(s + 3 * b), c->n, 0,
+                                 eps * eps, c->scal + 1, 0);
+  if (rc) return rc;
+  double h[2];
+  NB_HIP(c, hipMemcpyAsync(h, c->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  if (kinetic) *kinetic = h[0];
+  if (potential) *potential = -0.5 * G * h[1];
+  return NB_OK;
+}
+
+/* ---------------- device-pointer surface ---------------- */
+
+int nb_accel_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const void* zi, int64_t n_snk,
+                 const void* xs, const void* ys, const void* zs, const void* ms, int64_t n_src,
+                 double eps, double G, void* ax, void* ay, void* az, int accumulate) {
+  if (!c) return NB_ERR_ARG;
+  if (n_snk < 0 || n_src < 0) return nb_fail(c, NB_ERR_ARG, "nb_accel_dev: negative count");
+  if (n_snk > 0 && (!xi || !yi || !zi || !ax || !ay || !az)) return nb_fail(c, NB_ERR_ARG, "nb_accel_dev: NULL sink array");
+  if (n_src > 0 && (!xs || !ys || !zs || !ms)) return nb_fail(c, NB_ERR_ARG, "nb_accel_dev: NULL source array");
+  if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_accel_dev: eps must be >= 0");
+  int rc = use_device(c); if (rc) return rc;
+  if (dtype == NB_F32)
+    return nb_launch_accel_f32(c, (const float*)xi, (const float*)yi, (const float*)zi, n_snk, (const float*)xs,
+                               (const float*)ys, (const float*)zs, (const float*)ms, n_src, (float)(eps * eps),
+                               (float)G, (float*)ax, (float*)ay, (float*)az, accumulate);
+  if (dtype == NB_F64)
+    return nb_launch_accel_f64(c, (const double*)xi, (const double*)yi, (const double*)zi, n_snk, (const double*)xs,
+                               (const double*)ys, (const double*)zs, (const double*)ms, n_src, eps * eps, G,
+                               (double*)ax, (double*)ay, (double*)az, accumulate);
+  return nb_fail(c, NB_ERR_ARG, "nb_accel_dev: unknown dtype");
+}
+
+int nb_potential_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const void* zi, const void* mi,
+                     int64_t n_snk, int64_t snk_global0, const void* xs, const void* ys, const void* zs,
+                     const void* ms, int64_t n_src, int64_t src_global0, double eps, double* u_out, int accumulate) {
+  if (!c) return NB_ERR_ARG;
+  if (!u_out) return nb_fail(c, NB_ERR_ARG, "nb_potential_dev: u_out is NULL");
+  if (n_snk < 0 || n_src < 0) return nb_fail(c, NB_ERR_ARG, "nb_potential_dev: negative count");
+  if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_potential_dev: eps must be >= 0");
+  int rc = use_device(c); if (rc) return rc;
+  if (dtype == NB_F32)
+    return nb_launch_potential_f32(c, (const float*)xi, (const float*)yi, (const float*)zi, (const float*)mi, n_snk,
+                                   snk_global0, (const float*)xs, (const float*)ys, (const float*)zs,
+                                   (const float*)ms, n_src, src_global0, (float)(eps * eps), u_out, accumulate);
+  if (dtype == NB_F64)
+    return nb_launch_potential_f64(c, (const double*)xi, (const double*)yi, (const double*)zi, (const double*)mi,
+                                   n_snk, snk_global0, (const double*)xs, (const double*)ys, (const double*)zs,
+                                   (const double*)ms, n_src, src_global0, eps * eps, u_out, accumulate);
+  return nb_fail(c, NB_ERR_ARG, "nb_potential_dev: unknown dtype");
+}
+
+int nb_kinetic_dev(nb_ctx* c, int dtype, const void* vx, const void* vy, const void* vz, const void* m, int64_t n,
+                   double* k_out) {
+  if (!c) return NB_ERR_ARG;
+  if (!k_out || n < 0) return nb_fail(c, NB_ERR_ARG, "nb_kinetic_dev: bad argument");
+  if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_kinetic_dev: unknown dtype");
+  int rc = use_device(c); if (rc) return rc;
+  return nb_launch_kinetic(c, dtype, vx, vy, vz, m, n, k_out);
+}
+
+int nb_kick_dev(nb_ctx* c, int dtype, void* vx, void* vy, void* vz, const void* ax, const void* ay, const void* az,
+                int64_t n, double h) {
+  if (!c) return NB_ERR_ARG;
+  if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_kick_dev: unknown dtype");
+  int rc = use_device(c); if (rc) return rc;
+  return nb_launch_kick(c, dtype, vx, vy, vz, ax, ay, az, n, h);
+}
+
+int nb_drift_dev(nb_ctx* c, int dtype, void* x, void* y, void* z, const void* vx, const void* vy, const void* vz,
+                 int64_t n, double dt) {
+  if (!c) return NB_ERR_ARG;
+  if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_drift_dev: unknown dtype");
+  int rc = use_device(c); if (rc) return rc;
+  return nb_launch_drift(c, dtype, x, y, z, vx, vy, vz, n, dt);
+}
+
+}  // extern "C"

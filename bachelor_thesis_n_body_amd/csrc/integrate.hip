@@ -1,0 +1,156 @@
+// O(N) streaming kernels of the KDK leapfrog (SURVEY.md §8a row ⊕2) and the kinetic-energy reduction
+// (row ⊕3). HBM-bound: 28-56 B per particle per step; they exist so that nb_step() never leaves the
+// device. Products and sums are rounded separately (no FMA contraction) so that, given the same
+// accelerations, the fp64 integrator state is bit-identical to the NumPy oracle's `v += a*h; x += v*dt`.
+#include "nb_common.h"
+#include "../../include/nbody_amd.h"
+
+namespace {
+
+#pragma clang fp contract(off)
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+kick_kernel(T* __restrict__ vx, T* __restrict__ vy, T* __restrict__ vz, const T* __restrict__ ax,
+            const T* __restrict__ ay, const T* __restrict__ az, int64_t n, T h) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    vx[i] = vx[i] + ax[i] * h;
+    vy[i] = vy[i] + ay[i] * h;
+    vz[i] = vz[i] + az[i] * h;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+drift_kernel(T* __restrict__ x, T* __restrict__ y, T* __restrict__ z, const T* __restrict__ vx,
+             const T* __restrict__ vy, const T* __restrict__ vz, int64_t n, T dt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    x[i] = x[i] + vx[i] * dt;
+    y[i] = y[i] + vy[i] * dt;
+    z[i] = z[i] + vz[i] * dt;
+  }
+}
+
+// closing half-kick of step k, opening half-kick of step k+1 and its drift in one pass over the state:
+//   v += a*h1 ; v += a*h2 ; x += v*dt      (h1 = 0 for the very first step)
+template <typename T>
+__global__ void __launch_bounds__(256)
+kick_drift_kernel(T* __restrict__ x, T* __restrict__ y, T* __restrict__ z, T* __restrict__ vx,
+                  T* __restrict__ vy, T* __restrict__ vz, const T* __restrict__ ax, const T* __restrict__ ay,
+                  const T* __restrict__ az, int64_t n, T h1, T h2, T dt, int two) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    T a0 = ax[i], a1 = ay[i], a2 = az[i];
+    T v0 = vx[i], v1 = vy[i], v2 = vz[i];
+    if (two) { v0 = v0 + a0 * h1; v1 = v1 + a1 * h1; v2 = v2 + a2 * h1; }
+    v0 = v0 + a0 * h2; v1 = v1 + a1 * h2; v2 = v2 + a2 * h2;
+    vx[i] = v0; vy[i] = v1; vz[i] = v2;
+    x[i] = x[i] + v0 * dt; y[i] = y[i] + v1 * dt; z[i] = z[i] + v2 * dt;
+  }
+}
+
+// per-block fp64 partial of sum m v^2 / 2 -> part[blockIdx.x]; fixed-order final pass below
+template <typename T>
+__global__ void __launch_bounds__(256)
+kinetic_partial_kernel(const T* __restrict__ vx, const T* __restrict__ vy, const T* __restrict__ vz,
+                       const T* __restrict__ m, int64_t n, double* __restrict__ part) {
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double a = (double)vx[i], b = (double)vy[i], c = (double)vz[i];
+    s += (double)m[i] * (a * a + b * b + c * c);
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = 0.5 * red[0];
+}
+
+// out[0] = (accumulate ? out[0] : 0) + scale * sum_b part[b]     (single block, fixed order)
+__global__ void __launch_bounds__(256)
+final_sum_kernel(const double* __restrict__ part, int nparts, double scale, double* __restrict__ out,
+                    int accumulate) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nparts; b += 256) s += part[b];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0) + scale * red[0];
+}
+
+}  // namespace
+
+int nb_launch_final_sum(nb_ctx* c, const double* part, int nparts, double scale, double* out, int accumulate) {
+  final_sum_kernel<<<1, 256, 0, c->stream>>>(part, nparts, scale, out, accumulate);
+  NB_HIP(c, hipGetLastError());
+  return NB_OK;
+}
+
+static inline int stream_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));  // <= 8 blocks per CU, grid-stride the rest
+}
+
+int nb_launch_kick(nb_ctx* c, int dtype, void* vx, void* vy, void* vz, const void* ax, const void* ay,
+                   const void* az, int64_t n, double h) {
+  if (n <= 0) return NB_OK;
+  if (dtype == NB_F32)
+    kick_kernel<float><<<stream_grid(n), 256, 0, c->stream>>>((float*)vx, (float*)vy, (float*)vz, (const float*)ax,
+                                                              (const float*)ay, (const float*)az, n, (float)h);
+  else
+    kick_kernel<double><<<stream_grid(n), 256, 0, c->stream>>>((double*)vx, (double*)vy, (double*)vz, (const double*)ax,
+                                                               (const double*)ay, (const double*)az, n, h);
+  NB_HIP(c, hipGetLastError());
+  return NB_OK;
+}
+
+int nb_launch_drift(nb_ctx* c, int dtype, void* x, void* y, void* z, const void* vx, const void* vy,
+                    const void* vz, int64_t n, double dt) {
+  if (n <= 0) return NB_OK;
+  if (dtype == NB_F32)
+    drift_kernel<float><<<stream_grid(n), 256, 0, c->stream>>>((float*)x, (float*)y, (float*)z, (const float*)vx,
+                                                               (const float*)vy, (const float*)vz, n, (float)dt);
+  else
+    drift_kernel<double><<<stream_grid(n), 256, 0, c->stream>>>((double*)x, (double*)y, (double*)z, (const double*)vx,
+                                                                (const double*)vy, (const double*)vz, n, dt);
+  NB_HIP(c, hipGetLastError());
+  return NB_OK;
+}
+
+int nb_launch_kick_drift(nb_ctx* c, int dtype, void* x, void* y, void* z, void* vx, void* vy, void* vz,
+                         const void* ax, const void* ay, const void* az, int64_t n, double h1, double h2, double dt) {
+  if (n <= 0) return NB_OK;
+  const int two = h1 != 0.0;
+  if (dtype == NB_F32)
+    kick_drift_kernel<float><<<stream_grid(n), 256, 0, c->stream>>>(
+        (float*)x, (float*)y, (float*)z, (float*)vx, (float*)vy, (float*)vz, (const float*)ax, (const float*)ay,
+        (const float*)az, n, (float)h1, (float)h2, (float)dt, two);
+  else
+    kick_drift_kernel<double><<<stream_grid(n), 256, 0, c->stream>>>(
+        (double*)x, (double*)y, (double*)z, (double*)vx, (double*)vy, (double*)vz, (const double*)ax,
+        (const double*)ay, (const double*)az, n, h1, h2, dt, two);
+  NB_HIP(c, hipGetLastError());
+  return NB_OK;
+}
+
+int nb_launch_kinetic(nb_ctx* c, int dtype, const void* vx, const void* vy, const void* vz, const void* m,
+                      int64_t n, double* k_out) {
+  const int grid = stream_grid(n);
+  int rc = nb_ensure_work(c, (size_t)grid * sizeof(double));
+  if (rc) return rc;
+  double* part = reinterpret_cast<double*>(c->work);
+  if (dtype == NB_F32)
+    kinetic_partial_kernel<float><<<grid, 256, 0, c->stream>>>((const float*)vx, (const float*)vy, (const float*)vz,
+                                                               (const float*)m, n, part);
+  else
+    kinetic_partial_kernel<double><<<grid, 256, 0, c->stream>>>((const double*)vx, (const double*)vy,
+                                                                (const double*)vz, (const double*)m, n, part);
+  NB_HIP(c, hipGetLastError());
+  return nb_launch_final_sum(c, part, grid, 1.0, k_out, 0);
+}

@@ -1,0 +1,61 @@
+// Shared declarations for the HIP side of libnbody_amd.so (gfx950 only).
+// Internal header: the public C-ABI lives in include/nbody_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+
+struct nb_ctx {
+  int device = 0;
+  int dtype = 0;              // NB_F32 / NB_F64
+  int64_t n = 0;              // particles owned by this context
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // SoA state, one allocation: [x y z m | vx vy vz | ax ay az], each of length n (element = float or double)
+  void* state = nullptr;
+  bool has_state = false;
+  bool acc_valid = false;     // ax,ay,az hold a(x) for the current positions and (eps, G) below
+  double acc_eps = -1.0, acc_G = 0.0;
+  // scratch: split-source partial sums and block-level reductions
+  void* work = nullptr;
+  size_t work_bytes = 0;
+  double* scal = nullptr;     // device scalars (energy reductions)
+  std::string err;
+};
+
+// element pointer helpers into the SoA state block
+template <typename T> static inline T* st_ptr(nb_ctx* c, int field) {  // 0..9 = x y z m vx vy vz ax ay az
+  return reinterpret_cast<T*>(c->state) + (size_t)field * (size_t)c->n;
+}
+
+int nb_fail(nb_ctx* c, int code, const std::string& msg);
+int nb_ensure_work(nb_ctx* c, size_t bytes);
+
+#define NB_HIP(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  return nb_fail((c), NB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+// launchers (defined in the kernel translation units); all asynchronous on c->stream
+int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, int64_t n_snk,
+                        const float* xs, const float* ys, const float* zs, const float* ms, int64_t n_src,
+                        float eps2, float G, float* ax, float* ay, float* az, int accumulate);
+int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const double* zi, int64_t n_snk,
+                        const double* xs, const double* ys, const double* zs, const double* ms, int64_t n_src,
+                        double eps2, double G, double* ax, double* ay, double* az, int accumulate);
+int nb_launch_potential_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, const float* mi,
+                            int64_t n_snk, int64_t snk_global0, const float* xs, const float* ys, const float* zs,
+                            const float* ms, int64_t n_src, int64_t src_global0, float eps2, double* u_out,
+                            int accumulate);
+int nb_launch_potential_f64(nb_ctx* c, const double* xi, const double* yi, const double* zi, const double* mi,
+                            int64_t n_snk, int64_t snk_global0, const double* xs, const double* ys, const double* zs,
+                            const double* ms, int64_t n_src, int64_t src_global0, double eps2, double* u_out,
+                            int accumulate);
+// out[0] = (accumulate ? out[0] : 0) + scale * sum(part[0..nparts)), one block, fixed order
+int nb_launch_final_sum(nb_ctx* c, const double* part, int nparts, double scale, double* out, int accumulate);
+int nb_launch_kinetic(nb_ctx* c, int dtype, const void* vx, const void* vy, const void* vz, const void* m,
+                      int64_t n, double* k_out);
+int nb_launch_kick(nb_ctx* c, int dtype, void* vx, void* vy, void* vz, const void* ax, const void* ay,
+                   const void* az, int64_t n, double h);
+int nb_launch_drift(nb_ctx* c, int dtype, void* x, void* y, void* z, const void* vx, const void* vy,
+                    const void* vz, int64_t n, double dt);
+int nb_launch_kick_drift(nb_ctx* c, int dtype, void* x, void* y, void* z, void* vx, void* vy, void* vz,
+                         const void* ax, const void* ay, const void* az, int64_t n, double h1, double h2, double dt);

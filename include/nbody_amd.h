@@ -1,0 +1,99 @@
+/* nbody_amd.h — C-ABI of libnbody_amd.so: MI355X (gfx950) direct-summation N-body engine.
+ *
+ * What this boundary replaces in the reference (HusseinYoud/Bachelor-Thesis-N-Body):
+ * the reference has NO in-process force/integrator interface. Its only
+ * boundary to a direct-summation solver is process-level — a CONCEPT `pp` run spawned as
+ *     subprocess.check_call([concept, "-p", param, "-n", "1", "--local"], ...)
+ * at SnapVsPK/Ucertain.py:89-97 and TheFeedingPipeline/NeuNetværk_test.py:155-171, selected by
+ * `select_forces = {'matter': {'gravity': 'pp'}}` (pattern: Different_Sizes/Giant.param:66-68),
+ * with particle state exchanged as HDF5 `components/matter/{pos,mom}` (readers:
+ * SnapVsPK/Power_compare.py:143-144, TheFeedingPipeline/FraP_kTilDelta.py:55-68).
+ * The entry points below are the in-process surface that SURVEY.md §8(a) rows ⊕1-⊕3 define
+ * for that path (compute_forces / step / energy) — what a ctypes binding on the reference's
+ * Python side would call instead of spawning the external solver.
+ *
+ * Conventions
+ *  - plain C, no exceptions cross the ABI; every function returns 0 on success, <0 on error
+ *    (NB_ERR_*); nb_last_error(ctx) returns the message of the last failure.
+ *  - dtype: NB_F32 or NB_F64 selects the element type of every `void*` array of a context.
+ *  - arrays are structure-of-arrays: separate x, y, z, (m) pointers, `n` contiguous elements.
+ *  - a_i = G * sum_j m_j (r_j - r_i) / (|r_j - r_i|^2 + eps^2)^{3/2}   (Plummer softening;
+ *    pairs with |r_j - r_i|^2 + eps^2 == 0 contribute nothing), SURVEY.md §7.2.
+ *  - step = kick-drift-kick leapfrog, one force evaluation per step, acceleration cached.
+ *  - a context is bound to one GPU and is NOT thread-safe; one context per host thread.
+ *  - "_dev" functions take DEVICE pointers (e.g. torch tensors' data_ptr()) and enqueue on the
+ *    context's stream without synchronising; the others take HOST pointers and copy.
+ */
+#ifndef NBODY_AMD_H
+#define NBODY_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nb_ctx nb_ctx;
+
+enum { NB_F32 = 0, NB_F64 = 1 };
+enum {
+  NB_OK = 0,
+  NB_ERR_ARG = -1,      /* bad argument (null pointer, n <= 0, unknown dtype ...) */
+  NB_ERR_HIP = -2,      /* a HIP runtime call or kernel launch failed */
+  NB_ERR_NODEVICE = -3, /* no gfx950 device visible / bad device index */
+  NB_ERR_STATE = -4     /* call order violated (e.g. nb_step before nb_set_state) */
+};
+
+/* library / device discovery */
+int nb_version(void);                       /* 10000*major + 100*minor + patch */
+int nb_device_count(void);                  /* number of visible HIP devices, <0 on error */
+const char* nb_last_error(const nb_ctx* ctx); /* ctx may be NULL: error of the last failed nb_create */
+
+/* lifetime: `n` particles owned (integrated) by this context, on HIP device `device` */
+int nb_create(nb_ctx** out, int64_t n, int dtype, int device);
+int nb_destroy(nb_ctx* ctx);
+/* run all subsequent work on the caller's hipStream_t (e.g. torch's current stream) instead of the private
+ * stream created by nb_create; the handle is used as given, NULL being HIP's default (null) stream */
+int nb_set_stream(nb_ctx* ctx, void* hip_stream);
+int nb_synchronize(nb_ctx* ctx);
+
+/* ---- host-pointer surface: the drop-in compute_forces()/step()/energy() (SURVEY §8a ⊕1-⊕3) ---- */
+int nb_set_state(nb_ctx* ctx, const void* x, const void* y, const void* z,
+                 const void* vx, const void* vy, const void* vz, const void* m);
+int nb_get_state(nb_ctx* ctx, void* x, void* y, void* z, void* vx, void* vy, void* vz, void* m);
+/* acceleration of the context's particles due to themselves; ax/ay/az are host outputs (may be NULL
+ * to only refresh the cached device-side acceleration) */
+int nb_accel(nb_ctx* ctx, double eps, double G, void* ax, void* ay, void* az);
+/* copy out the cached acceleration (valid after nb_accel or nb_step; NB_ERR_STATE otherwise) */
+int nb_get_acc(nb_ctx* ctx, void* ax, void* ay, void* az);
+/* nsteps KDK steps of size dt, entirely on the device (no host round trip inside the loop) */
+int nb_step(nb_ctx* ctx, double dt, int64_t nsteps, double eps, double G);
+/* kinetic and softened potential energy, accumulated in fp64 */
+int nb_energy(nb_ctx* ctx, double eps, double G, double* kinetic, double* potential);
+
+/* ---- device-pointer surface: building blocks for the sink-decomposed multi-GPU path ---- */
+/* acc[i] (+)= G * sum_{j<n_src} m_j (r_j - r_i)/(r_ij^2+eps^2)^{3/2} for i < n_snk.
+ * accumulate != 0 adds to the existing ax/ay/az (used when source chunks arrive one ring hop at a time). */
+int nb_accel_dev(nb_ctx* ctx, int dtype,
+                 const void* xi, const void* yi, const void* zi, int64_t n_snk,
+                 const void* xs, const void* ys, const void* zs, const void* ms, int64_t n_src,
+                 double eps, double G, void* ax, void* ay, void* az, int accumulate);
+/* u_out[0] (+)= sum_i m_i sum_{j != i (by global index)} m_j / sqrt(r_ij^2+eps^2)   (device double;
+ * the caller applies -G/2). snk_global0 / src_global0 are the global indices of element 0 of each set. */
+int nb_potential_dev(nb_ctx* ctx, int dtype,
+                     const void* xi, const void* yi, const void* zi, const void* mi, int64_t n_snk,
+                     int64_t snk_global0,
+                     const void* xs, const void* ys, const void* zs, const void* ms, int64_t n_src,
+                     int64_t src_global0, double eps, double* u_out, int accumulate);
+/* k_out[0] = sum_i m_i |v_i|^2 / 2 (device double) */
+int nb_kinetic_dev(nb_ctx* ctx, int dtype, const void* vx, const void* vy, const void* vz,
+                   const void* m, int64_t n, double* k_out);
+/* v += a*h ; x += v*dt  (each product and sum rounded separately, like the NumPy oracle) */
+int nb_kick_dev(nb_ctx* ctx, int dtype, void* vx, void* vy, void* vz,
+                const void* ax, const void* ay, const void* az, int64_t n, double h);
+int nb_drift_dev(nb_ctx* ctx, int dtype, void* x, void* y, void* z,
+                 const void* vx, const void* vy, const void* vz, int64_t n, double dt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_AMD_H */
