@@ -29,13 +29,8 @@ namespace {
 
 constexpr int BLOCK = 256;
 typedef float v2f __attribute__((ext_vector_type(2)));
-#ifndef NB_F32_UNROLL
-#define NB_F32_UNROLL 4
-#endif
-#define NB_PRAGMA_(x) _Pragma(#x)
-#define NB_UNROLL(n) NB_PRAGMA_(unroll n)
 
-template <int KS, int TILE, bool GUARD>
+template <int KS, int U, int TILE, bool GUARD>
 __global__ void __launch_bounds__(BLOCK)
 accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, const float* __restrict__ zi,
                  int n_snk,
@@ -52,6 +47,7 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
   const int i0 = blockIdx.x * (BLOCK * KS) + tid;
 
   static_assert(KS % 2 == 0, "sinks are processed as packed pairs");
+  static_assert(TILE % U == 0, "tile must be a multiple of the source group");
   constexpr int KP = KS / 2;
   // sink pair p = sinks (2p, 2p+1) of this lane: one 64-bit VGPR pair per coordinate -> v_pk_* math
   v2f px[KP], py[KP], pz[KP];
@@ -104,28 +100,48 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
 #pragma unroll
     for (int p = 0; p < KP; ++p) { fx[p] = v2f{0.f, 0.f}; fy[p] = v2f{0.f, 0.f}; fz[p] = v2f{0.f, 0.f}; }
 
-    NB_UNROLL(NB_F32_UNROLL)
-    for (int j = 0; j < TILE; ++j) {
-      const float4 s = tile[buf][j];  // wave-uniform address: LDS broadcast
-      const v2f sx = v2f{s.x, s.x}, sy = v2f{s.y, s.y}, sz = v2f{s.z, s.z}, sm = v2f{s.w, s.w};
+    // U sources x KP sink pairs = U*KP independent dependency chains per group, written breadth-first (all
+    // chains do stage 1, then all do stage 2, ...) so that a wave never issues an instruction that needs the
+    // result of the one just before it: the pk ops of other chains fill the v_rsq_f32 latency.
+    for (int j = 0; j < TILE; j += U) {
+      float4 s[U];
 #pragma unroll
-      for (int p = 0; p < KP; ++p) {
-        const v2f dx = sx - px[p];
-        const v2f dy = sy - py[p];
-        const v2f dz = sz - pz[p];
-        const v2f r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, e2)));
-        v2f rinv = v2f{__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
-        if (GUARD) {  // coincident pair (dx=dy=dz=0): contributes nothing
-          rinv.x = r2.x > e2.x ? rinv.x : 0.0f;
-          rinv.y = r2.y > e2.y ? rinv.y : 0.0f;
+      for (int u = 0; u < U; ++u) s[u] = tile[buf][j + u];  // wave-uniform address: LDS broadcast
+      v2f dx[U][KP], dy[U][KP], dz[U][KP], r2[U][KP], rinv[U][KP];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+          dx[u][p] = v2f{s[u].x, s[u].x} - px[p];
+          dy[u][p] = v2f{s[u].y, s[u].y} - py[p];
+          dz[u][p] = v2f{s[u].z, s[u].z} - pz[p];
         }
-        const v2f rinv2 = rinv * rinv;
-        const v2f mr = sm * rinv;
-        const v2f f = mr * rinv2;
-        fx[p] = __builtin_elementwise_fma(f, dx, fx[p]);
-        fy[p] = __builtin_elementwise_fma(f, dy, fy[p]);
-        fz[p] = __builtin_elementwise_fma(f, dz, fz[p]);
-      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int p = 0; p < KP; ++p)
+          r2[u][p] = __builtin_elementwise_fma(dx[u][p], dx[u][p], __builtin_elementwise_fma(dy[u][p], dy[u][p], __builtin_elementwise_fma(dz[u][p], dz[u][p], e2)));
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+          rinv[u][p] = v2f{__builtin_amdgcn_rsqf(r2[u][p].x), __builtin_amdgcn_rsqf(r2[u][p].y)};
+          if (GUARD) {  // coincident pair (dx=dy=dz=0): contributes nothing
+            rinv[u][p].x = r2[u][p].x > e2.x ? rinv[u][p].x : 0.0f;
+            rinv[u][p].y = r2[u][p].y > e2.y ? rinv[u][p].y : 0.0f;
+          }
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+          const v2f rinv2 = rinv[u][p] * rinv[u][p];
+          const v2f mr = v2f{s[u].w, s[u].w} * rinv[u][p];
+          const v2f f = mr * rinv2;
+          fx[p] = __builtin_elementwise_fma(f, dx[u][p], fx[p]);
+          fy[p] = __builtin_elementwise_fma(f, dy[u][p], fy[p]);
+          fz[p] = __builtin_elementwise_fma(f, dz[u][p], fz[p]);
+        }
     }
 #pragma unroll
     for (int p = 0; p < KP; ++p) {
@@ -180,16 +196,16 @@ int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
-template <int KS, int TILE>
+template <int KS, int U, int TILE>
 void launch_variant(bool guard, dim3 grid, hipStream_t st, const float* xi, const float* yi, const float* zi,
                     int n_snk, const float* xs, const float* ys, const float* zs, const float* ms, int n_src,
                     int sps, float eps2, float G, float* ax, float* ay, float* az, double* part, int accumulate) {
   if (guard)
-    accel_f32_kernel<KS, TILE, true><<<grid, BLOCK, 0, st>>>(xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps, eps2, G,
-                                                            ax, ay, az, part, accumulate);
+    accel_f32_kernel<KS, U, TILE, true><<<grid, BLOCK, 0, st>>>(xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps, eps2, G,
+                                                               ax, ay, az, part, accumulate);
   else
-    accel_f32_kernel<KS, TILE, false><<<grid, BLOCK, 0, st>>>(xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps, eps2, G,
-                                                             ax, ay, az, part, accumulate);
+    accel_f32_kernel<KS, U, TILE, false><<<grid, BLOCK, 0, st>>>(xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps, eps2, G,
+                                                                ax, ay, az, part, accumulate);
 }
 
 }  // namespace
@@ -228,11 +244,21 @@ int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float
   }
   const bool guard = !(eps2 >= 1e-20f);
   dim3 grid(nblk, nsplit);
-  switch (ks) {
-    case 2: launch_variant<2, TILE>(guard, grid, c->stream, xi, yi, zi, (int)n_snk, xs, ys, zs, ms, (int)n_src, sps, eps2, G, ax, ay, az, part, accumulate); break;
-    case 8: launch_variant<8, TILE>(guard, grid, c->stream, xi, yi, zi, (int)n_snk, xs, ys, zs, ms, (int)n_src, sps, eps2, G, ax, ay, az, part, accumulate); break;
-    default: launch_variant<4, TILE>(guard, grid, c->stream, xi, yi, zi, (int)n_snk, xs, ys, zs, ms, (int)n_src, sps, eps2, G, ax, ay, az, part, accumulate); break;
+  int u = env_int("NB_F32_U", 0);
+  if (u != 1 && u != 2 && u != 4) u = 2;
+#define NB_GO(K, UU) launch_variant<K, UU, TILE>(guard, grid, c->stream, xi, yi, zi, (int)n_snk, xs, ys, zs, ms, (int)n_src, sps, eps2, G, ax, ay, az, part, accumulate)
+  switch (ks * 10 + u) {
+    case 21: NB_GO(2, 1); break;
+    case 22: NB_GO(2, 2); break;
+    case 24: NB_GO(2, 4); break;
+    case 41: NB_GO(4, 1); break;
+    case 42: NB_GO(4, 2); break;
+    case 44: NB_GO(4, 4); break;
+    case 81: NB_GO(8, 1); break;
+    case 82: NB_GO(8, 2); break;
+    default: NB_GO(8, 1); break;
   }
+#undef NB_GO
   NB_HIP(c, hipGetLastError());
   if (nsplit > 1) {
     accel_reduce_f32_kernel<<<(int)((n_snk + 255) / 256), 256, 0, c->stream>>>(part, nsplit, (int)n_snk, G, ax, ay, az, accumulate);

@@ -155,6 +155,7 @@ class ShardedEngine:
         self.gathered = z(self.world, 4, self.n_max) if (self.world > 1 and mode == "allgather") else None
         self.scal = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._acc_key = None
+        self.kernel_timer = None   # optional object with begin()/end(interactions): brackets every accel launch
 
     # -- state ----------------------------------------------------------------------------------
     def set_state(self, state: State) -> None:
@@ -179,7 +180,7 @@ class ShardedEngine:
         for src in (self.pm, self.vel, self.acc):
             if self.world > 1:
                 out = t.empty((self.world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
-                dist.all_gather_into_tensor(out, src.contiguous(), group=self.group)
+                dist.all_gather_into_tensor(out.view(-1), src.contiguous().view(-1), group=self.group)
             else:
                 out = src.unsqueeze(0)
             blocks.append(out.cpu().numpy())
@@ -199,7 +200,7 @@ class ShardedEngine:
             fn(self.pm, r, True)
             return
         if self.mode == "allgather":
-            work = dist.all_gather_into_tensor(self.gathered, self.pm, group=self.group, async_op=True)
+            work = dist.all_gather_into_tensor(self.gathered.view(-1), self.pm.view(-1), group=self.group, async_op=True)
             fn(self.pm, r, True)          # own chunk overlaps the collective
             work.wait()
             for h in range(1, P):
@@ -224,8 +225,14 @@ class ShardedEngine:
 
     def accel(self, eps: float, G: float = 1.0) -> None:
         """acc <- a(x) of the owned sinks due to ALL particles."""
+        tm = self.kernel_timer
+
         def one(src, owner, first):
+            if tm is not None:
+                tm.begin()
             self.k.accel(self.pm, self.n_loc, src, self.counts[owner], eps, G, self.acc, not first)
+            if tm is not None:
+                tm.end(float(self.n_loc) * float(self.counts[owner]))
         self._for_each_chunk(one)
         self._acc_key = (eps, G)
 

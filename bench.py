@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particle-pair interactions per second of the direct-summation KDK step.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1: plain python; N > 1: under torch.distributed.run)
+
+Workload (BASELINE.json metric): Plummer sphere, N = 2^20 particles, fp32, Hénon units, equal
+masses, eps = 0.01, dt = 1/256, seed 0 — synthetic, generated on the host and resident in HBM before the timed
+region. One "step" is one kick-drift-kick step = one all-pairs force evaluation (N^2 ordered interactions) plus
+the O(N) kick/drift kernels and, for N > 1 GPUs, the ring exchange of source chunks (sink decomposition, strong
+scaling: the total problem is fixed, every rank owns N/P sinks).
+
+Rank 0 prints ONE JSON line. Besides the contract's keys it carries
+  roofline     — the dominant kernel (accel_f32_kernel) against the gfx950 vector-FP32 peak, at the conventional
+                 20 flop per interaction; durations from HIP events on the launch stream
+  cpu_baseline — the C oracle (oracle/nbody_oracle.c, OpenMP, fp64) timed on this host on a bounded sample of the
+                 same workload (the first M sinks against all N sources), rank 0 / 1 GPU only.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+FLOP_PER_INTERACTION = 20.0        # Nyland-Harris-Prins convention, SURVEY.md §8(d)
+PEAK_FP32_VECTOR_TFLOPS = 157.3    # MI355X_MICROARCH.md "Peak FP32 (vector)"
+PEAK_FP64_VECTOR_TFLOPS = 78.6
+
+
+class KernelTimer:
+    """HIP-event pairs around every accel launch, recorded on the stream the kernels run on (torch's current
+    stream, which the engine binds with nb_set_stream)."""
+
+    def __init__(self, torch):
+        self.torch, self.pairs, self.enabled = torch, [], False
+
+    def begin(self):
+        if self.enabled:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._open = e
+
+    def end(self, interactions):
+        if self.enabled:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.pairs.append((self._open, e, interactions))
+
+    def summary(self):
+        ms = [a.elapsed_time(b) for a, b, _ in self.pairs]
+        inter = [i for _, _, i in self.pairs]
+        return (sum(ms) / len(ms), sum(inter) / len(inter), len(ms)) if ms else (0.0, 0.0, 0)
+
+
+def cpu_baseline(state, eps, budget_s=12.0):
+    """C oracle, fp64, OpenMP over sinks: first M sinks of the workload against all N sources."""
+    threads = min(16, os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    so = ROOT / "oracle" / "libnbody_oracle.so"
+    if not so.exists():
+        return None
+    lib = C.CDLL(str(so))
+    threads = int(lib.nbo_max_threads())
+    p = np.ascontiguousarray(state.pos.T.astype(np.float64))
+    m = np.ascontiguousarray(state.mass.astype(np.float64))
+    n = p.shape[1]
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def run(m_snk):
+        a = np.empty((3, m_snk))
+        t0 = time.perf_counter()
+        lib.nbo_accel_f64_omp(C.c_int64(m_snk), vp(p[0]), vp(p[1]), vp(p[2]), C.c_int64(n), vp(p[0]), vp(p[1]), vp(p[2]),
+                              vp(m), C.c_double(eps), C.c_double(1.0), vp(a[0]), vp(a[1]), vp(a[2]))
+        return time.perf_counter() - t0
+
+    probe = max(threads * 4, 64)
+    run(probe)                                  # warm the threads
+    t = run(probe)
+    rate = probe * n / t
+    m_snk = int(min(n, max(probe, (budget_s * rate / n) // threads * threads)))
+    t = run(m_snk)
+    return {"value": m_snk * n / t, "unit": "interactions/s", "cores": threads, "kind": "port",
+            "sample": f"C oracle fp64 OpenMP: first {m_snk} sinks x all {n} sources of the same Plummer workload, {t:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1 << 20)
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--mode", choices=["ring", "allgather"], default="ring")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import bachelor_thesis_n_body_amd as nb
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} disagrees with WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    np_dtype = np.float32 if args.dtype == "f32" else np.float64
+    eps, dt, G = 0.01, 1.0 / 256.0, 1.0
+    state = nb.plummer_sphere(args.n, seed=0, dtype=np_dtype)
+    eng = nb.ShardedEngine(args.n, np_dtype, device=torch.device("cuda", local_rank), mode=args.mode)
+    eng.set_state(state)
+    timer = KernelTimer(torch)
+    eng.kernel_timer = timer
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    eng.accel(eps, G)                      # initial a(x): not part of a step
+    for _ in range(args.warmup):
+        eng.step(dt, 1, eps, G)
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step(dt, 1, eps, G)
+    sync()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    interactions = float(args.n) * float(args.n) * args.steps
+    value = interactions / elapsed
+    k_ms, k_inter, k_count = timer.summary()
+    peak = PEAK_FP32_VECTOR_TFLOPS if args.dtype == "f32" else PEAK_FP64_VECTOR_TFLOPS
+    achieved = k_inter * FLOP_PER_INTERACTION / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "particle-pair interactions/s",
+            "value": value,
+            "unit": "interactions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"plummer_sphere N={args.n} {args.dtype} eps=0.01 dt=1/256, KDK step = 1 all-pairs force evaluation",
+                       "n": args.n, "parallelism": f"sink-decomposition x{world}, {args.mode} exchange of source chunks"},
+            "roofline": {"bound": "vector_" + ("fp32" if args.dtype == "f32" else "fp64"),
+                         "kernel": "accel_%s_kernel" % args.dtype,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "flop_per_interaction": FLOP_PER_INTERACTION,
+                         "interactions_per_launch": k_inter, "avg_launch_ms": k_ms, "launches_timed": k_count,
+                         "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(state, eps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+"""World-size-2 (and 3, uneven) rehearsal of the sink-decomposed path on CPU with the gloo backend: the ring
+exchange, partitioning, accumulate-over-chunks and the energy all-reduce are the product code; only the
+arithmetic is stubbed by the oracle (tests/cpu_kernels.py). Results must match the single-process oracle."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, mode, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bachelor_thesis_n_body_amd as nb
+        from cpu_kernels import OracleKernels
+        eps, dt = 0.02, 1 / 128
+        s = nb.plummer_sphere(n, 5)
+        s.mass = s.mass * np.random.default_rng(1).uniform(0.5, 2.0, n)   # unequal masses
+        eng = nb.ShardedEngine(n, np.float64, device="cpu", kernels=OracleKernels(), mode=mode)
+        assert sum(eng.counts) == n and eng.n_loc == eng.counts[rank]
+        eng.set_state(s)
+        eng.accel(eps)
+        acc0 = eng.gather_state().acc
+        k0, u0 = eng.energy(eps)
+        eng.step(dt, 3, eps)
+        st = eng.gather_state()
+        k1, u1 = eng.energy(eps)
+        if rank == 0:
+            np.savez(Path(out_dir) / "res.npz", acc0=acc0, pos=st.pos, vel=st.vel, mass=st.mass, acc=st.acc,
+                     e=np.array([k0, u0, k1, u1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,mode", [(2, 96, "ring"), (2, 97, "allgather"), (3, 50, "ring")])
+def test_sharded_engine_matches_single_process_oracle(tmp_path, world, n, mode):
+    from oracle import nbody_oracle as ora
+    import bachelor_thesis_n_body_amd as nb
+    mp.spawn(_worker, args=(world, _free_port(), n, mode, str(tmp_path)), nprocs=world, join=True)
+    r = np.load(tmp_path / "res.npz")
+    eps, dt = 0.02, 1 / 128
+    s = nb.plummer_sphere(n, 5)
+    mass = s.mass * np.random.default_rng(1).uniform(0.5, 2.0, n)
+    o = ora.State(s.pos.copy(), s.vel.copy(), mass)
+    np.testing.assert_allclose(r["acc0"], ora.compute_forces(o.pos, o.mass, eps), rtol=1e-12, atol=1e-14)
+    k0, u0 = ora.energy(o, eps)
+    ora.step(o, dt, 3, eps=eps)
+    k1, u1 = ora.energy(o, eps)
+    np.testing.assert_allclose(r["pos"], o.pos, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(r["vel"], o.vel, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(r["acc"], o.acc, rtol=1e-11, atol=1e-13)
+    np.testing.assert_array_equal(r["mass"], mass)
+    np.testing.assert_allclose(r["e"], [k0, u0, k1, u1], rtol=1e-12)
+
+
+def test_single_rank_engine_without_process_group():
+    """world = 1 needs no torch.distributed initialisation (bench.py --gpus 1 path)."""
+    import bachelor_thesis_n_body_amd as nb
+    from cpu_kernels import OracleKernels
+    from oracle import nbody_oracle as ora
+    s = nb.plummer_sphere(40, 2)
+    eng = nb.ShardedEngine(40, np.float64, device="cpu", kernels=OracleKernels())
+    eng.set_state(s)
+    eng.step(0.01, 2, 0.05)
+    o = ora.State(s.pos.copy(), s.vel.copy(), s.mass.copy())
+    ora.step(o, 0.01, 2, eps=0.05)
+    np.testing.assert_allclose(eng.gather_state().pos, o.pos, rtol=1e-13, atol=1e-15)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        nb.ShardedEngine(40, np.float64, device="cpu")          # no silent CPU path in the product

@@ -1,0 +1,142 @@
+"""Pins the CPU oracle (NumPy and C restatements) with the analytic known-answer tests of SURVEY.md §8(c)
+items 1-7. The reference holds no fixture for this path ("parity unpinned", oracle/nbody_oracle.py header), so
+these closed forms are what anchors the checker that the GPU parity tests then trust."""
+import numpy as np
+import pytest
+
+from oracle import nbody_oracle as ora
+from bachelor_thesis_n_body_amd import plummer_sphere, PLUMMER_A
+
+
+def both(coracle):
+    return [("numpy", lambda p, m, e, G=1.0: ora.compute_forces(p, m, e, G)),
+            ("c-omp", lambda p, m, e, G=1.0: coracle.accel(p, m, e, G)),
+            ("c-seq", lambda p, m, e, G=1.0: coracle.accel(p, m, e, G, sequential=True))]
+
+
+def test_two_body_closed_form(coracle):
+    # KAT 1: |a| = G m d / (d^2 + eps^2)^{3/2}, equal and opposite (weighted by mass)
+    pos = np.array([[0.0, 0.0, 0.0], [0.3, -0.4, 1.2]])
+    mass = np.array([2.0, 5.0])
+    d = pos[1] - pos[0]
+    for eps in (0.0, 0.05, 1.0):
+        for G in (1.0, 4.3e-3):
+            w = G / (d @ d + eps * eps) ** 1.5
+            for name, f in both(coracle):
+                a = f(pos, mass, eps, G)
+                np.testing.assert_allclose(a[0], w * mass[1] * d, rtol=1e-14, err_msg=name)
+                np.testing.assert_allclose(a[1], -w * mass[0] * d, rtol=1e-14, err_msg=name)
+
+
+def test_newton_third_law(coracle):
+    # KAT 2: total momentum change vanishes to round-off
+    s = plummer_sphere(2048, 3)
+    for name, f in both(coracle):
+        a = f(s.pos, s.mass, 0.01)
+        net = np.abs((s.mass[:, None] * a).sum(0)).max()
+        scale = (s.mass[:, None] * np.abs(a)).sum(0).max()
+        assert net <= 1e-13 * scale, name
+
+
+def test_plummer_mean_field():
+    # KAT 3: radially binned <a_r> follows -G M r / (r^2 + a^2)^{3/2} within sampling noise
+    n = 4096
+    s = plummer_sphere(n, 2)
+    a = ora.compute_forces(s.pos, s.mass, 0.01)
+    r = np.linalg.norm(s.pos, axis=1)
+    a_r = np.einsum("ij,ij->i", a, s.pos) / r
+    edges = np.quantile(r, np.linspace(0.05, 0.9, 9))
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        sel = (r >= lo) & (r < hi)
+        model = -(r[sel]) / (r[sel] ** 2 + PLUMMER_A ** 2) ** 1.5
+        assert abs(a_r[sel].mean() / model.mean() - 1.0) < 0.08
+
+
+def test_large_softening_limit(coracle):
+    # KAT 4: eps >> system size: a_i -> G (sum_j m_j r_j - M r_i) / eps^3
+    s = plummer_sphere(512, 4)
+    eps = 1e5
+    expect = ((s.mass[:, None] * s.pos).sum(0)[None, :] - s.mass.sum() * s.pos) / eps ** 3
+    for name, f in both(coracle):
+        np.testing.assert_allclose(f(s.pos, s.mass, eps), expect, rtol=1e-6, atol=1e-6 * np.abs(expect).max(), err_msg=name)
+
+
+def test_permutation_and_translation_invariance(coracle):
+    # KAT 5
+    s = plummer_sphere(700, 5)
+    perm = np.random.default_rng(0).permutation(s.n)
+    shift = np.array([3.0, -2.0, 0.5])
+    for name, f in both(coracle):
+        a = f(s.pos, s.mass, 0.02)
+        np.testing.assert_allclose(f(s.pos[perm], s.mass[perm], 0.02), a[perm], rtol=1e-11, atol=1e-13, err_msg=name)
+        np.testing.assert_allclose(f(s.pos + shift, s.mass, 0.02), a, rtol=1e-9, atol=1e-12, err_msg=name)
+
+
+def test_restatements_agree(coracle):
+    # three independent implementations of the same definition
+    for n, eps in ((1, 0.1), (2, 0.0), (3, 0.01), (257, 0.01), (1500, 0.0)):
+        s = plummer_sphere(n, 10 + n)
+        ref = ora.compute_forces(s.pos, s.mass, eps)
+        np.testing.assert_allclose(coracle.accel(s.pos, s.mass, eps), ref, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(coracle.accel(s.pos, s.mass, eps, sequential=True), ref, rtol=1e-11, atol=1e-13)
+        assert coracle.potential(s.pos, s.mass, eps) == pytest.approx(ora.potential_energy(s.pos, s.mass, eps), rel=1e-12)
+        assert coracle.kinetic(s.vel, s.mass) == pytest.approx(ora.kinetic_energy(s.vel, s.mass), rel=1e-13)
+
+
+def test_coincident_and_empty_inputs(coracle):
+    # zero-denominator pairs are skipped; empty source/sink sets give zeros
+    pos = np.array([[1.0, 2.0, 3.0], [1.0, 2.0, 3.0], [0.0, 0.0, 0.0]])
+    mass = np.array([1.0, 1.0, 1.0])
+    for name, f in both(coracle):
+        a = f(pos, mass, 0.0)
+        assert np.all(np.isfinite(a)), name
+        np.testing.assert_allclose(a[0], a[1], rtol=0, atol=0)
+    assert ora.compute_forces(np.zeros((0, 3)), np.zeros(0), 0.1).shape == (0, 3)
+    assert np.all(ora.compute_forces(np.zeros((0, 3)), np.zeros(0), 0.1, sinks=np.ones((4, 3))) == 0.0)
+
+
+def test_kdk_time_reversibility():
+    # KAT 6a: n steps forward, flip v, n steps -> initial state to round-off
+    s0 = plummer_sphere(128, 6)
+    s = ora.State(s0.pos.copy(), s0.vel.copy(), s0.mass.copy())
+    ora.step(s, 1 / 128, 40, eps=0.05)
+    s.vel *= -1.0
+    ora.step(s, 1 / 128, 40, eps=0.05)
+    np.testing.assert_allclose(s.pos, s0.pos, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(-s.vel, s0.vel, rtol=0, atol=1e-11)
+
+
+def test_kdk_second_order_energy_error():
+    # KAT 6b: halving dt quarters the energy error
+    s0 = plummer_sphere(256, 7)
+    eps, T = 0.05, 0.5
+    errs = []
+    for nsteps in (16, 32, 64):
+        s = ora.State(s0.pos.copy(), s0.vel.copy(), s0.mass.copy())
+        k0, u0 = ora.energy(s, eps)
+        ora.step(s, T / nsteps, nsteps, eps=eps)
+        k1, u1 = ora.energy(s, eps)
+        errs.append(abs((k1 + u1) - (k0 + u0)))
+    assert 3.0 < errs[0] / errs[1] < 5.5
+    assert 3.0 < errs[1] / errs[2] < 5.5
+
+
+def test_kdk_circular_two_body_period():
+    # KAT 6c: equal masses m on a circle of separation d: omega^2 = G (2m) / d^3
+    m, d = 0.5, 1.0
+    omega = np.sqrt(2 * m / d ** 3)
+    v = 0.5 * d * omega
+    s = ora.State(np.array([[-d / 2, 0, 0], [d / 2, 0, 0.0]]), np.array([[0, -v, 0], [0, v, 0.0]]), np.array([m, m]))
+    nsteps = 4000
+    ora.step(s, 2 * np.pi / omega / nsteps, nsteps, eps=0.0)
+    np.testing.assert_allclose(s.pos, [[-d / 2, 0, 0], [d / 2, 0, 0]], atol=2e-5)
+
+
+def test_plummer_virial_and_energy(coracle):
+    # KAT 7: 2K/|U| ~ 1 and E ~ -1/4 in Hénon units
+    s = plummer_sphere(8192, 8)
+    k = coracle.kinetic(s.vel, s.mass)
+    u = coracle.potential(s.pos, s.mass, 0.0)
+    assert abs(2 * k / abs(u) - 1.0) < 0.05
+    assert abs((k + u) + 0.25) < 0.02
+    # the radius cut at 10a removes ~1% of the mass from the tail: U is slightly shallower than -1/2... checked loosely
