@@ -62,12 +62,17 @@ class KernelTimer:
 
 def cpu_baseline(state, eps, budget_s=12.0):
     """C oracle, fp64, OpenMP over sinks: first M sinks of the workload against all N sources."""
-    threads = min(16, os.cpu_count() or 1)
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     so = ROOT / "oracle" / "libnbody_oracle.so"
     if not so.exists():
         return None
     lib = C.CDLL(str(so))
+    # one GPU's share of the host: 16 cores (libgomp is already initialised by torch, so set it explicitly)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(16, avail))
+    lib.nbo_set_threads(C.c_int(threads))
     threads = int(lib.nbo_max_threads())
     p = np.ascontiguousarray(state.pos.T.astype(np.float64))
     m = np.ascontiguousarray(state.mass.astype(np.float64))

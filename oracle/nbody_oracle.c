@@ -39,6 +39,14 @@ void nbo_accel_f64(int64_t n_snk, const double* xi, const double* yi, const doub
   }
 }
 
+void nbo_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int nbo_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
