@@ -216,16 +216,17 @@ int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float
   if (n_snk <= 0) return NB_OK;
   if (n_snk >= (1ll << 31) || n_src >= (1ll << 31)) return nb_fail(c, NB_ERR_ARG, "n must be < 2^31");
   constexpr int TILE = 512;
-  // sinks per lane: 4 once there are enough sinks to fill the chip with 1024-sink blocks, fewer below that
+  // sinks per lane: 8 (four packed pairs) as soon as there are enough sinks to fill lanes; measured on MI355X
+  // (profiles/r01_tune_f32.txt) KS=8/U=2 with many source splits is fastest from N = 2^14 to 2^20.
   int ks = env_int("NB_F32_KS", 0);
-  if (ks != 2 && ks != 4 && ks != 8) ks = n_snk >= 256 * 1024 ? 4 : 2;
+  if (ks != 2 && ks != 4 && ks != 8) ks = n_snk >= 16384 ? 8 : (n_snk >= 4096 ? 4 : 2);
   const int spb = BLOCK * ks;
   const int nblk = (int)((n_snk + spb - 1) / spb);
-  // split the source range so that the grid has >= ~8 blocks per CU (256 CUs) when sinks alone cannot
+  // split the source range so that the grid has ~16 blocks per CU (256 CUs) when sinks alone cannot
   int nsplit = env_int("NB_F32_SPLIT", 0);
   const int ntiles_total = (int)((n_src + TILE - 1) / TILE);
   if (nsplit <= 0) {
-    const int target_blocks = 2048;
+    const int target_blocks = 4096;
     nsplit = nblk >= target_blocks ? 1 : (target_blocks + nblk - 1) / nblk;
   }
   if (nsplit > ntiles_total) nsplit = ntiles_total > 0 ? ntiles_total : 1;

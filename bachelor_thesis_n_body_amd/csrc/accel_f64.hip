@@ -3,11 +3,11 @@
 // Same structure as accel_f32.hip (SoA sinks in VGPRs, sources re-packed to (x,y,z,m) in a
 // double-buffered LDS tile read with wave-uniform addresses, split-source slabs for small N), bounded by
 // the vector-FP64 rate (v_fma_f64 = half the fp32 rate). There is no packed fp64 math and no fast fp64
-// rsqrt, so 1/sqrt(r^2) is a hardware seed refined by ONE Halley step (cubic convergence):
-//     y0 = v_rsq_f64(r2)                       (~2^-26 relative)  [RSQ_MODE 0]
-//     y0 = (double) v_rsq_f32((float) r2)      (~2^-23 relative)  [RSQ_MODE 1; r2 must fit fp32 range]
-//     h  = 1 - r2*y0^2 ;  y = y0 * (1 + h/2 + 3h^2/8)            -> relative error ~ h^3 < 1e-20
-// Per interaction: 3 add, 3 fma, seed, 5 (Halley), 3 mul, 3 fma = 17 fp64 VALU + seed.
+// rsqrt, so m/r^3 is built from a hardware rsqrt seed and a second-order correction in h = 1 - r2*y^2:
+//     y  = v_rsq_f64(r2)                       (~2^-26 relative)  [RSQ_MODE 0]
+//     y  = (double) v_rsq_f32((float) r2)      (~2^-23 relative)  [RSQ_MODE 1; r2 must fit fp32 range]
+//     h  = 1 - r2*y^2 ;  m/r^3 = m y^3 (1 + 3h/2 + 15h^2/8)       -> relative error ~ 3h^3 < 1e-20
+// Per interaction: 3 add, 3 fma, seed, 7 (m/r^3), 3 fma = 16 fp64 VALU + seed.
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
 #include <cstdlib>
@@ -17,13 +17,19 @@ namespace {
 constexpr int BLOCK = 256;
 struct d4 { double x, y, z, w; };
 
+// m / (r2)^{3/2} from a hardware rsqrt seed y ~ r2^{-1/2}:  with h = 1 - r2*y^2,
+//   r2^{-3/2} = y^3 (1-h)^{-3/2} = y^3 (1 + 3/2 h + 15/8 h^2 + O(h^3)),   |h| <~ 2^-23  ->  error ~ 3 h^3 < 1e-20
+// 7 fp64 VALU ops after the seed (one fewer than refining y first and cubing afterwards).
 template <int RSQ_MODE>
-__device__ inline double rsqrt_f64(double r2) {
+__device__ inline double m_over_r3(double m, double r2) {
   double y;
-  if (RSQ_MODE == 0) y = __builtin_amdgcn_rsq(r2);
-  else y = (double)__builtin_amdgcn_rsqf((float)r2);
-  const double h = fma(-r2 * y, y, 1.0);
-  return y * fma(h, fma(0.375, h, 0.5), 1.0);
+  if (RSQ_MODE == 1) y = (double)__builtin_amdgcn_rsqf((float)r2);   // r2 must fit the fp32 range
+  else y = __builtin_amdgcn_rsq(r2);                                   // v_rsq_f64
+  const double y2 = y * y;
+  const double h = fma(-r2, y2, 1.0);
+  const double q = fma(fma(1.875, h, 1.5), h, 1.0);
+  const double my = m * y;
+  return (my * y2) * q;
 }
 
 template <int KS, int TILE, bool GUARD, int RSQ_MODE>
@@ -89,11 +95,8 @@ accel_f64_kernel(const double* __restrict__ xi, const double* __restrict__ yi, c
         const double dy = s.y - py[k];
         const double dz = s.z - pz[k];
         const double r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, e2)));
-        double rinv = rsqrt_f64<RSQ_MODE>(r2);
-        if (GUARD) rinv = r2 > e2 ? rinv : 0.0;
-        const double rinv2 = rinv * rinv;
-        const double mr = s.w * rinv;
-        const double f = mr * rinv2;
+        double f = m_over_r3<RSQ_MODE>(s.w, r2);
+        if (GUARD) f = r2 > e2 ? f : 0.0;   // coincident pair (dx=dy=dz=0) at eps = 0: contributes nothing
         fx[k] = fma(f, dx, fx[k]);
         fy[k] = fma(f, dy, fy[k]);
         fz[k] = fma(f, dz, fz[k]);
@@ -164,13 +167,13 @@ int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const dou
   if (n_snk >= (1ll << 31) || n_src >= (1ll << 31)) return nb_fail(c, NB_ERR_ARG, "n must be < 2^31");
   constexpr int TILE = 256;
   int ks = env_int("NB_F64_KS", 0);
-  if (ks != 1 && ks != 2 && ks != 4) ks = n_snk >= 128 * 1024 ? 2 : 1;
+  if (ks != 1 && ks != 2 && ks != 4) ks = n_snk >= 32768 ? 4 : (n_snk >= 8192 ? 2 : 1);
   const int rsq_mode = env_int("NB_F64_RSQ", 0);
   const int spb = BLOCK * ks;
   const int nblk = (int)((n_snk + spb - 1) / spb);
   int nsplit = env_int("NB_F64_SPLIT", 0);
   const int ntiles_total = (int)((n_src + TILE - 1) / TILE);
-  if (nsplit <= 0) nsplit = nblk >= 2048 ? 1 : (2048 + nblk - 1) / nblk;
+  if (nsplit <= 0) nsplit = nblk >= 4096 ? 1 : (4096 + nblk - 1) / nblk;
   if (nsplit > ntiles_total) nsplit = ntiles_total > 0 ? ntiles_total : 1;
   if (nsplit > 65535) nsplit = 65535;
   int tps = (ntiles_total + nsplit - 1) / nsplit;

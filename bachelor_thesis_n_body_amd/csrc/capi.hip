@@ -3,6 +3,7 @@
 // stream with no host round trip inside nb_step().
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -17,6 +18,8 @@ int nb_ensure_work(nb_ctx* c, size_t bytes) {
   if (bytes <= c->work_bytes) return NB_OK;
   // earlier kernels on the stream may still read the old buffer
   NB_HIP(c, hipStreamSynchronize(c->stream));
+  // a captured step graph holds the old scratch pointer
+  if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
   if (c->work) { NB_HIP(c, hipFree(c->work)); c->work = nullptr; c->work_bytes = 0; }
   size_t want = bytes + bytes / 4;
   NB_HIP(c, hipMalloc(&c->work, want));
@@ -85,6 +88,7 @@ int nb_destroy(nb_ctx* c) {
   if (!c) return NB_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
   if (c->state) (void)hipFree(c->state);
   if (c->work) (void)hipFree(c->work);
   if (c->scal) (void)hipFree(c->scal);
@@ -97,6 +101,7 @@ int nb_set_stream(nb_ctx* c, void* hip_stream) {
   if (!c) return NB_ERR_ARG;
   int rc = use_device(c); if (rc) return rc;
   NB_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
   // the handle is used as given; NULL is HIP's default (null) stream, which is what torch's default stream is
   if (c->own_stream) { NB_HIP(c, hipStreamDestroy(c->stream)); c->own_stream = false; }
   c->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -198,7 +203,30 @@ int nb_step(nb_ctx* c, double dt, int64_t nsteps, double eps, double G) {
   void *x = s, *y = s + b, *z = s + 2 * b, *vx = s + 4 * b, *vy = s + 5 * b, *vz = s + 6 * b;
   void *ax = s + 7 * b, *ay = s + 8 * b, *az = s + 9 * b;
   const double h = 0.5 * dt;
+  // Launch-bound regime (small N, many steps): steps 1..n-1 are identical launch sequences
+  // [kick_drift(h, h, dt); a(x)] with constant arguments, so capture one into a hipGraph and replay it.
+  static const bool no_graph = getenv("NB_NO_GRAPH") != nullptr;
+  const bool use_graph = !no_graph && c->n <= 65536 && nsteps >= 4;
   for (int64_t k = 0; k < nsteps; ++k) {
+    if (use_graph && k >= 1) {
+      if (!c->step_graph || c->graph_dt != dt || c->graph_eps != eps || c->graph_G != G) {
+        if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
+        // step 0 ran eagerly above, so the scratch buffer already has its final size: no allocation in capture
+        hipGraph_t g = nullptr;
+        NB_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        rc = nb_launch_kick_drift(c, c->dtype, x, y, z, vx, vy, vz, ax, ay, az, c->n, h, h, dt);
+        if (!rc) rc = refresh_acc(c, eps, G);
+        hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return nb_fail(c, NB_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        e = hipGraphInstantiate(&c->step_graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) { c->step_graph = nullptr; return nb_fail(c, NB_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+        c->graph_dt = dt; c->graph_eps = eps; c->graph_G = G;
+      }
+      NB_HIP(c, hipGraphLaunch(c->step_graph, c->stream));
+      continue;
+    }
     // step k: [closing half-kick of step k-1, fused] opening half-kick, drift; force; (closing kick deferred)
     rc = nb_launch_kick_drift(c, c->dtype, x, y, z, vx, vy, vz, ax, ay, az, c->n, k == 0 ? 0.0 : h, h, dt);
     if (rc) return rc;

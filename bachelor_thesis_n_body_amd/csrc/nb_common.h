@@ -20,6 +20,9 @@ struct nb_ctx {
   void* work = nullptr;
   size_t work_bytes = 0;
   double* scal = nullptr;     // device scalars (energy reductions)
+  // one KDK step [kick_drift(h,h,dt); a(x)] captured as a hipGraph and replayed for launch-bound (small-N) runs
+  hipGraphExec_t step_graph = nullptr;
+  double graph_dt = 0.0, graph_eps = -1.0, graph_G = 0.0;
   std::string err;
 };
 

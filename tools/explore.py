@@ -48,6 +48,12 @@ if __name__ == "__main__":
             for n in (65536, 1048576):
                 rate(n, np.float32, label=f"KS={ks} U={u}")
         os.environ.pop("NB_F32_KS"); os.environ.pop("NB_F32_U")
+    if what == "tune":
+        for n in (16384, 65536, 262144):
+            for ks, u in ((2, 2), (4, 2), (8, 2)):
+                for split in (0, 4, 8, 16, 32, 64):
+                    os.environ["NB_F32_KS"] = str(ks); os.environ["NB_F32_U"] = str(u); os.environ["NB_F32_SPLIT"] = str(split)
+                    rate(n, np.float32, reps=5, label=f"KS={ks} U={u} SPLIT={split}")
     if what in ("all", "f64"):
         for mode in (0, 1):
             for ks in (1, 2, 4):
