@@ -10,13 +10,15 @@ Public surface (mirrors oracle/nbody_oracle.py so parity tests read the same on 
     plummer_sphere(n, seed)                       ⊕4
     Engine                                         resident single-GPU context (nb_ctx)
     ShardedEngine, partition                       sink decomposition over the GPUs of a node (§8e)
+    field, snapshot                                §8f-1/2: CIC density / deconvolution / P(k) on the GPU, CONCEPT snapshot I/O
 Everything computes on the GPU through libnbody_amd.so (include/nbody_amd.h); there is no CPU fallback.
 """
 from .state import State
 from .ics import plummer_sphere, PLUMMER_A
 from .api import Engine, compute_forces, step, energy
 from .dist import ShardedEngine, HipKernels, partition
+from . import field, snapshot
 
 __all__ = ["State", "plummer_sphere", "PLUMMER_A", "Engine", "compute_forces", "step", "energy",
-           "ShardedEngine", "HipKernels", "partition"]
+           "ShardedEngine", "HipKernels", "partition", "field", "snapshot"]
 __version__ = "0.1.0"

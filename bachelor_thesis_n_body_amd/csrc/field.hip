@@ -1,0 +1,352 @@
+// Snapshot -> density-field chain on gfx950 (C-ABI in include/nbody_field.h).
+//
+// Kernels (all HBM / atomic bound, fp64 like the reference):
+//   cic_kernel        one lane per particle: cell index and CIC weights computed with the reference's exact
+//                     expressions (FraP_kTilDelta.py:100-121: int(p/cell) % N, (p % cell)/cell, (wx*wy)*wz), eight
+//                     global_atomic_add_f64 per particle. 24 B read + 8 atomics per particle.
+//   affine_kernel     grid = (grid/div1)/div2 - sub (compute_delta, FraP_kTilDelta.py:126-127)
+//   r2c / window / c2r kernels around hipFFT Z2Z: delta_k /= W, W = ((w[i]*w[j])*w[k])^2 (FraP_kTilDelta.py:73-91)
+//   power_bin_kernel  |delta_k|^2 * scale binned by |k| = sqrt((kx^2+ky^2)+kz^2) into host-supplied edges with
+//                     np.histogram's semantics (Power_compare.py:176-198); integer counts are exact.
+// Compiled with -ffp-contract=off: products and sums round separately, as NumPy's do.
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include "../../include/nbody_amd.h"
+#include "../../include/nbody_field.h"
+
+struct nbf_plan {
+  int device = 0, ngrid = 0;
+  double boxsize = 0.0;
+  size_t cells = 0;
+  double* grid = nullptr;            // [ngrid^3] real
+  hipfftDoubleComplex* cgrid = nullptr;   // [ngrid^3] complex
+  double* w1d = nullptr;             // [ngrid]
+  double* kvals = nullptr;           // [ngrid]
+  double* edges = nullptr;           // [nedges]
+  int nedges = 0;
+  double* psum = nullptr;            // [nedges-1]
+  unsigned long long* counts = nullptr;
+  double* pos = nullptr;             // device staging for positions
+  size_t pos_cap = 0;
+  double* part = nullptr;            // reduction partials
+  hipfftHandle fft = 0;
+  bool have_fft = false;
+  hipStream_t stream = nullptr;
+  std::string err;
+};
+
+static thread_local std::string g_field_err;
+
+static int ffail(nbf_plan* p, int code, const std::string& m) {
+  if (p) p->err = m; else g_field_err = m;
+  return code;
+}
+#define F_HIP(p, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  return ffail((p), NB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+#define F_FFT(p, call) do { hipfftResult r_ = (call); if (r_ != HIPFFT_SUCCESS) \
+  return ffail((p), NB_ERR_HIP, std::string(#call) + ": hipfft error " + std::to_string((int)r_)); } while (0)
+
+namespace {
+
+// Python's float modulo: result takes the sign of the divisor
+__device__ inline double py_mod(double x, double y) {
+  double r = fmod(x, y);
+  if (r != 0.0 && ((r < 0.0) != (y < 0.0))) r += y;
+  return r;
+}
+// int(x) % N with Python semantics (truncate toward zero, non-negative remainder)
+__device__ inline int py_cell(double x, double cell, int N) {
+  long long i = (long long)(x / cell);
+  long long r = i % N;
+  if (r < 0) r += N;
+  return (int)r;
+}
+
+__global__ void __launch_bounds__(256)
+cic_kernel(const double* __restrict__ pos, long long n, double cell, int N, double* __restrict__ grid) {
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+    const double x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+    const int i = py_cell(x, cell, N), j = py_cell(y, cell, N), k = py_cell(z, cell, N);
+    const double dx = py_mod(x, cell) / cell, dy = py_mod(y, cell) / cell, dz = py_mod(z, cell) / cell;
+#pragma unroll
+    for (int di = 0; di < 2; ++di) {
+      const double wx = di ? dx : 1.0 - dx;
+      const int ni = (i + di) % N;
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        const double wy = dj ? dy : 1.0 - dy;
+        const int nj = (j + dj) % N;
+#pragma unroll
+        for (int dk = 0; dk < 2; ++dk) {
+          const double wz = dk ? dz : 1.0 - dz;
+          const int nk = (k + dk) % N;
+          atomicAdd(&grid[((size_t)ni * N + nj) * N + nk], (wx * wy) * wz);
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+sum_partial_kernel(const double* __restrict__ g, size_t n, double* __restrict__ part) {
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += g[i];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256)
+sum_final_kernel(const double* __restrict__ part, int nparts, double* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nparts; b += 256) s += part[b];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+__global__ void __launch_bounds__(256)
+affine_kernel(double* __restrict__ g, size_t n, double div1, double div2, double sub) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    g[i] = (g[i] / div1) / div2 - sub;
+}
+
+__global__ void __launch_bounds__(256)
+r2c_kernel(const double* __restrict__ g, hipfftDoubleComplex* __restrict__ c, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    c[i].x = g[i]; c[i].y = 0.0;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+window_kernel(hipfftDoubleComplex* __restrict__ c, const double* __restrict__ w1d, int N) {
+  const size_t n = (size_t)N * N * N;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % N), j = (int)((idx / N) % N), i = (int)(idx / ((size_t)N * N));
+    const double t = (w1d[i] * w1d[j]) * w1d[k];
+    double W = t * t;
+    if (W == 0.0) W = 1.0;
+    c[idx].x = c[idx].x / W;
+    c[idx].y = c[idx].y / W;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+c2r_kernel(const hipfftDoubleComplex* __restrict__ c, double* __restrict__ g, size_t n, double scale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    g[i] = c[i].x * scale;
+}
+
+__global__ void __launch_bounds__(256)
+power_bin_kernel(const hipfftDoubleComplex* __restrict__ c, const double* __restrict__ kv, const double* __restrict__ edges,
+                 int nedges, int N, double scale, double* __restrict__ psum, unsigned long long* __restrict__ counts) {
+  const size_t n = (size_t)N * N * N;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % N), j = (int)((idx / N) % N), i = (int)(idx / ((size_t)N * N));
+    const double kx = kv[i], ky = kv[j], kz = kv[k];
+    const double km = sqrt((kx * kx + ky * ky) + kz * kz);
+    if (!(km > 0.0) || km < edges[0] || km > edges[nedges - 1]) continue;
+    // np.histogram: bin b holds edges[b] <= x < edges[b+1]; the last bin also holds x == edges[-1]
+    int lo = 0, hi = nedges;                 // first edge > km
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (edges[mid] <= km) lo = mid + 1; else hi = mid; }
+    int b = lo - 1;
+    if (b >= nedges - 1) b = nedges - 2;
+    const double re = c[idx].x, im = c[idx].y;
+    atomicAdd(&psum[b], (re * re + im * im) * scale);
+    atomicAdd(&counts[b], 1ull);
+  }
+}
+
+inline int grid_for(size_t n) {
+  size_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+int use_dev(nbf_plan* p) { F_HIP(p, hipSetDevice(p->device)); return NB_OK; }
+
+int forward_fft(nbf_plan* p) {
+  r2c_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->grid, p->cgrid, p->cells);
+  F_HIP(p, hipGetLastError());
+  F_FFT(p, hipfftExecZ2Z(p->fft, p->cgrid, p->cgrid, HIPFFT_FORWARD));
+  return NB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nbf_last_error(const nbf_plan* p) { return p ? p->err.c_str() : g_field_err.c_str(); }
+
+int nbf_create(nbf_plan** out, int ngrid, double boxsize, int device) {
+  if (!out) return ffail(nullptr, NB_ERR_ARG, "nbf_create: out is NULL");
+  *out = nullptr;
+  if (ngrid < 1 || ngrid > 2048) return ffail(nullptr, NB_ERR_ARG, "nbf_create: ngrid must be in [1, 2048]");
+  if (!(boxsize > 0.0)) return ffail(nullptr, NB_ERR_ARG, "nbf_create: boxsize must be > 0");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return ffail(nullptr, NB_ERR_NODEVICE, std::string("nbf_create: no HIP device visible (") + hipGetErrorString(e) + ")");
+  if (device < 0 || device >= ndev) return ffail(nullptr, NB_ERR_NODEVICE, "nbf_create: device index out of range");
+  nbf_plan* p = new (std::nothrow) nbf_plan();
+  if (!p) return ffail(nullptr, NB_ERR_ARG, "nbf_create: out of host memory");
+  p->device = device; p->ngrid = ngrid; p->boxsize = boxsize; p->cells = (size_t)ngrid * ngrid * ngrid;
+  auto bail = [&](const std::string& m) { std::string msg = m; nbf_destroy(p); return ffail(nullptr, NB_ERR_HIP, msg); };
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail(std::string("hipSetDevice: ") + hipGetErrorString(e));
+  if ((e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate failed");
+  if ((e = hipMalloc((void**)&p->grid, p->cells * sizeof(double))) != hipSuccess) return bail("hipMalloc(grid) failed");
+  if ((e = hipMalloc((void**)&p->cgrid, p->cells * sizeof(hipfftDoubleComplex))) != hipSuccess) return bail("hipMalloc(cgrid) failed");
+  if ((e = hipMalloc((void**)&p->w1d, ngrid * sizeof(double))) != hipSuccess) return bail("hipMalloc(w1d) failed");
+  if ((e = hipMalloc((void**)&p->kvals, ngrid * sizeof(double))) != hipSuccess) return bail("hipMalloc(kvals) failed");
+  if ((e = hipMalloc((void**)&p->part, 4096 * sizeof(double))) != hipSuccess) return bail("hipMalloc(part) failed");
+  if ((e = hipMemset(p->grid, 0, p->cells * sizeof(double))) != hipSuccess) return bail("hipMemset failed");
+  hipfftResult r = hipfftPlan3d(&p->fft, ngrid, ngrid, ngrid, HIPFFT_Z2Z);
+  if (r != HIPFFT_SUCCESS) return bail("hipfftPlan3d failed: " + std::to_string((int)r));
+  p->have_fft = true;
+  if ((r = hipfftSetStream(p->fft, p->stream)) != HIPFFT_SUCCESS) return bail("hipfftSetStream failed");
+  *out = p;
+  return NB_OK;
+}
+
+int nbf_destroy(nbf_plan* p) {
+  if (!p) return NB_OK;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  if (p->have_fft) (void)hipfftDestroy(p->fft);
+  void* bufs[] = {p->grid, p->cgrid, p->w1d, p->kvals, p->edges, p->psum, p->counts, p->pos, p->part};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+  return NB_OK;
+}
+
+int nbf_set_window(nbf_plan* p, const double* w1d) {
+  if (!p || !w1d) return ffail(p, NB_ERR_ARG, "nbf_set_window: NULL argument");
+  int rc = use_dev(p); if (rc) return rc;
+  F_HIP(p, hipMemcpyAsync(p->w1d, w1d, p->ngrid * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  F_HIP(p, hipStreamSynchronize(p->stream));
+  return NB_OK;
+}
+
+int nbf_set_kbins(nbf_plan* p, const double* kvals, const double* edges, int nedges) {
+  if (!p || !kvals || !edges) return ffail(p, NB_ERR_ARG, "nbf_set_kbins: NULL argument");
+  if (nedges < 2) return ffail(p, NB_ERR_ARG, "nbf_set_kbins: need at least 2 edges");
+  int rc = use_dev(p); if (rc) return rc;
+  F_HIP(p, hipStreamSynchronize(p->stream));
+  if (p->edges) { F_HIP(p, hipFree(p->edges)); p->edges = nullptr; }
+  if (p->psum) { F_HIP(p, hipFree(p->psum)); p->psum = nullptr; }
+  if (p->counts) { F_HIP(p, hipFree(p->counts)); p->counts = nullptr; }
+  F_HIP(p, hipMalloc((void**)&p->edges, nedges * sizeof(double)));
+  F_HIP(p, hipMalloc((void**)&p->psum, (nedges - 1) * sizeof(double)));
+  F_HIP(p, hipMalloc((void**)&p->counts, (nedges - 1) * sizeof(unsigned long long)));
+  p->nedges = nedges;
+  F_HIP(p, hipMemcpyAsync(p->kvals, kvals, p->ngrid * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  F_HIP(p, hipMemcpyAsync(p->edges, edges, nedges * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  F_HIP(p, hipStreamSynchronize(p->stream));
+  return NB_OK;
+}
+
+int nbf_cic(nbf_plan* p, const double* pos, int64_t n) {
+  if (!p) return NB_ERR_ARG;
+  if (n < 0 || (n > 0 && !pos)) return ffail(p, NB_ERR_ARG, "nbf_cic: bad positions");
+  int rc = use_dev(p); if (rc) return rc;
+  const size_t need = (size_t)n * 3 * sizeof(double);
+  if (need > p->pos_cap) {
+    F_HIP(p, hipStreamSynchronize(p->stream));
+    if (p->pos) { F_HIP(p, hipFree(p->pos)); p->pos = nullptr; p->pos_cap = 0; }
+    F_HIP(p, hipMalloc((void**)&p->pos, need));
+    p->pos_cap = need;
+  }
+  if (n > 0) F_HIP(p, hipMemcpyAsync(p->pos, pos, need, hipMemcpyHostToDevice, p->stream));
+  F_HIP(p, hipMemsetAsync(p->grid, 0, p->cells * sizeof(double), p->stream));
+  if (n > 0) {
+    cic_kernel<<<grid_for((size_t)n), 256, 0, p->stream>>>(p->pos, (long long)n, p->boxsize / p->ngrid, p->ngrid, p->grid);
+    F_HIP(p, hipGetLastError());
+  }
+  F_HIP(p, hipStreamSynchronize(p->stream));   // the caller may free `pos` after return
+  return NB_OK;
+}
+
+int nbf_grid_mean(nbf_plan* p, double* mean) {
+  if (!p || !mean) return ffail(p, NB_ERR_ARG, "nbf_grid_mean: NULL argument");
+  int rc = use_dev(p); if (rc) return rc;
+  const int g = grid_for(p->cells);
+  sum_partial_kernel<<<g, 256, 0, p->stream>>>(p->grid, p->cells, p->part);
+  F_HIP(p, hipGetLastError());
+  sum_final_kernel<<<1, 256, 0, p->stream>>>(p->part, g, p->part + g);
+  F_HIP(p, hipGetLastError());
+  double s = 0.0;
+  F_HIP(p, hipMemcpyAsync(&s, p->part + g, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  F_HIP(p, hipStreamSynchronize(p->stream));
+  *mean = s / (double)p->cells;
+  return NB_OK;
+}
+
+int nbf_grid_affine(nbf_plan* p, double div1, double div2, double sub) {
+  if (!p) return NB_ERR_ARG;
+  int rc = use_dev(p); if (rc) return rc;
+  affine_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->grid, p->cells, div1, div2, sub);
+  F_HIP(p, hipGetLastError());
+  return NB_OK;
+}
+
+int nbf_deconvolve(nbf_plan* p) {
+  if (!p) return NB_ERR_ARG;
+  int rc = use_dev(p); if (rc) return rc;
+  rc = forward_fft(p); if (rc) return rc;
+  window_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->cgrid, p->w1d, p->ngrid);
+  F_HIP(p, hipGetLastError());
+  F_FFT(p, hipfftExecZ2Z(p->fft, p->cgrid, p->cgrid, HIPFFT_BACKWARD));
+  c2r_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->cgrid, p->grid, p->cells, 1.0 / (double)p->cells);
+  F_HIP(p, hipGetLastError());
+  return NB_OK;
+}
+
+int nbf_get_grid(nbf_plan* p, double* out) {
+  if (!p || !out) return ffail(p, NB_ERR_ARG, "nbf_get_grid: NULL argument");
+  int rc = use_dev(p); if (rc) return rc;
+  F_HIP(p, hipMemcpyAsync(out, p->grid, p->cells * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  F_HIP(p, hipStreamSynchronize(p->stream));
+  return NB_OK;
+}
+
+int nbf_set_grid(nbf_plan* p, const double* in) {
+  if (!p || !in) return ffail(p, NB_ERR_ARG, "nbf_set_grid: NULL argument");
+  int rc = use_dev(p); if (rc) return rc;
+  F_HIP(p, hipMemcpyAsync(p->grid, in, p->cells * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  F_HIP(p, hipStreamSynchronize(p->stream));
+  return NB_OK;
+}
+
+int nbf_power_bins(nbf_plan* p, double scale, double* psum, int64_t* counts) {
+  if (!p || !psum || !counts) return ffail(p, NB_ERR_ARG, "nbf_power_bins: NULL argument");
+  if (!p->edges) return ffail(p, NB_ERR_STATE, "nbf_power_bins: call nbf_set_kbins first");
+  int rc = use_dev(p); if (rc) return rc;
+  const int nb = p->nedges - 1;
+  rc = forward_fft(p); if (rc) return rc;
+  F_HIP(p, hipMemsetAsync(p->psum, 0, nb * sizeof(double), p->stream));
+  F_HIP(p, hipMemsetAsync(p->counts, 0, nb * sizeof(unsigned long long), p->stream));
+  power_bin_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->cgrid, p->kvals, p->edges, p->nedges, p->ngrid, scale,
+                                                              p->psum, p->counts);
+  F_HIP(p, hipGetLastError());
+  F_HIP(p, hipMemcpyAsync(psum, p->psum, nb * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  static_assert(sizeof(unsigned long long) == sizeof(int64_t), "count type");
+  F_HIP(p, hipMemcpyAsync(counts, p->counts, nb * sizeof(int64_t), hipMemcpyDeviceToHost, p->stream));
+  F_HIP(p, hipStreamSynchronize(p->stream));
+  return NB_OK;
+}
+
+}  // extern "C"

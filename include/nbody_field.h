@@ -1,0 +1,52 @@
+/* nbody_field.h — C-ABI of the snapshot -> density-field chain in libnbody_amd.so.
+ *
+ * What it replaces in the reference (pure-Python / numba loops + numpy FFTs):
+ *   cic_density(positions, boxsize, N)       TheFeedingPipeline/FraP_kTilDelta.py:93-123, SnapVsPK/Power_compare.py:100-132
+ *   compute_delta(density)                   TheFeedingPipeline/FraP_kTilDelta.py:126-127
+ *   deconvolve_cic(delta_grid, boxsize, N)   TheFeedingPipeline/FraP_kTilDelta.py:73-91, SnapVsPK/Power_compare.py:80-97
+ *   compute_power_spectrum_from_snapshot     SnapVsPK/Power_compare.py:135-200
+ * driven per snapshot by TheFeedingPipeline/Feeder_pipe.py:163-195.
+ *
+ * A plan owns an ngrid^3 real grid and an ngrid^3 complex grid in HBM plus a hipFFT Z2Z plan. The small 1-D tables
+ * (CIC window along one axis, k values along one axis, histogram edges) are computed by the HOST exactly as the
+ * reference computes them (numpy) and handed over, so that bin assignment is bit-identical; all O(N_particles) and
+ * O(ngrid^3) work runs on the GPU. Every function returns 0 on success, <0 (NB_ERR_* of nbody_amd.h) on failure;
+ * nbf_last_error gives the message. Host pointers unless stated otherwise; a plan is not thread-safe.
+ */
+#ifndef NBODY_FIELD_H
+#define NBODY_FIELD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nbf_plan nbf_plan;
+
+int nbf_create(nbf_plan** out, int ngrid, double boxsize, int device);
+int nbf_destroy(nbf_plan* plan);
+const char* nbf_last_error(const nbf_plan* plan);
+
+/* w1d[ngrid] = sinc(k/(2 k_Nyq)) along one axis (FraP_kTilDelta.py:73-81); W = ((w[i]*w[j])*w[k])^2, zeros -> 1 */
+int nbf_set_window(nbf_plan* plan, const double* w1d);
+/* kvals[ngrid] = 2*pi*fftfreq(ngrid, d); edges[nedges] = histogram bin edges (Power_compare.py:179-191) */
+int nbf_set_kbins(nbf_plan* plan, const double* kvals, const double* edges, int nedges);
+
+/* grid <- CIC deposit of n particles, pos = (n,3) f64 array-of-vectors as in `components/matter/pos` */
+int nbf_cic(nbf_plan* plan, const double* pos, int64_t n);
+/* mean of the real grid (fixed-order fp64 reduction) */
+int nbf_grid_mean(nbf_plan* plan, double* mean);
+/* grid <- (grid / div1) / div2 - sub      (compute_delta: div1 = mean, div2 = 1, sub = 1) */
+int nbf_grid_affine(nbf_plan* plan, double div1, double div2, double sub);
+/* grid <- real(ifftn(fftn(grid) / W)) */
+int nbf_deconvolve(nbf_plan* plan);
+/* copy the real grid out / in (ngrid^3 doubles, C order [i][j][k]) */
+int nbf_get_grid(nbf_plan* plan, double* out);
+int nbf_set_grid(nbf_plan* plan, const double* in);
+/* psum[nedges-1], counts[nedges-1] <- histogram over all modes of |fftn(grid)|^2 * scale, binned by |k| */
+int nbf_power_bins(nbf_plan* plan, double scale, double* psum, int64_t* counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_FIELD_H */

@@ -9,11 +9,12 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 HEADER = ROOT / "include" / "nbody_amd.h"
+FIELD_HEADER = ROOT / "include" / "nbody_field.h"
 
 
-def declared_functions():
-    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
-    return sorted(set(re.findall(r"\b(nb_[a-z0-9_]+)\s*\(", text)))
+def declared_functions(header=HEADER, prefix="nb_"):
+    text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_declares_expected_surface():
@@ -31,6 +32,12 @@ def test_library_exports_every_declared_symbol():
     # and the ctypes table binds exactly the header's functions
     assert sorted(_lib.SIGNATURES) == declared_functions()
     assert lib.nb_version() >= 100
+    from bachelor_thesis_n_body_amd import field
+    names = declared_functions(FIELD_HEADER, "nbf_")
+    assert len(names) >= 10
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/nbody_field.h but not exported"
+    assert sorted(field.FIELD_SIGNATURES) == names
 
 
 def test_abi_is_plain_c():
