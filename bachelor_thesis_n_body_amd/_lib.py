@@ -11,6 +11,7 @@ from pathlib import Path
 
 NB_F32, NB_F64 = 0, 1
 NB_OK = 0
+NB_ACCUMULATE, NB_UNIFORM_MASS = 1, 2
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libnbody_amd.so"

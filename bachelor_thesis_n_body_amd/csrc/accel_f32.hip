@@ -18,6 +18,9 @@
 //  * accuracy: fp32 partial sums live only for one source tile (TILE sources); at every tile boundary
 //    they are flushed into fp64 running totals (3*KS v_add_f64 per TILE*KS*13 VALU ops — free), which
 //    removes the O(sqrt(N)) growth of the fp32 accumulation error at N = 2^20.
+//  * uniform masses (flag NB_UNIFORM_MASS, the standard equal-mass N-body set-up — every CONCEPT run of the thesis):
+//    the per-source `m*rinv` multiply is dropped (11 instead of 12 full-rate ops) and the common mass is applied once
+//    with G in the fp64 epilogue; padding sources then sit at 1e18 so that rinv^3 underflows to exactly 0.
 //  * small N: the source range is split over gridDim.y so the grid still fills 256 CUs; partial sums go
 //    to an fp64 slab [split][3][n_snk] and a second tiny kernel reduces them in a fixed order
 //    (bit-reproducible — no float atomics).
@@ -30,7 +33,7 @@ namespace {
 constexpr int BLOCK = 256;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int KS, int U, int TILE, bool GUARD>
+template <int KS, int U, int TILE, bool GUARD, bool UNIFORM>
 __global__ void __launch_bounds__(BLOCK)
 accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, const float* __restrict__ zi,
                  int n_snk,
@@ -76,8 +79,11 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
       int j = jbeg + t * TILE + l * BLOCK + tid;
       bool ok = j < jend;
       int jc = ok ? j : jend - 1;
-      // padding sources carry zero mass: they add exactly 0 (their r^2 + eps^2 > 0, or GUARD zeroes them)
-      stage[l] = make_float4(xs[jc], ys[jc], zs[jc], ok ? ms[jc] : 0.0f);
+      // padding sources carry zero mass: they add exactly 0 (their r^2 + eps^2 > 0, or GUARD zeroes them).
+      // In UNIFORM mode the mass is not read per source, so padding sits at 1e18 instead: rinv^3 underflows to 0.
+      const float far = 1e18f;
+      stage[l] = UNIFORM ? make_float4(ok ? xs[jc] : far, ok ? ys[jc] : far, ok ? zs[jc] : far, 0.0f)
+                         : make_float4(xs[jc], ys[jc], zs[jc], ok ? ms[jc] : 0.0f);
     }
   };
   auto commit = [&](int buf) {
@@ -136,8 +142,9 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
 #pragma unroll
         for (int p = 0; p < KP; ++p) {
           const v2f rinv2 = rinv[u][p] * rinv[u][p];
-          const v2f mr = v2f{s[u].w, s[u].w} * rinv[u][p];
-          const v2f f = mr * rinv2;
+          v2f f;
+          if (UNIFORM) f = rinv2 * rinv[u][p];                                  // common mass applied once, at the end
+          else f = (v2f{s[u].w, s[u].w} * rinv[u][p]) * rinv2;
           fx[p] = __builtin_elementwise_fma(f, dx[u][p], fx[p]);
           fy[p] = __builtin_elementwise_fma(f, dy[u][p], fy[p]);
           fz[p] = __builtin_elementwise_fma(f, dz[u][p], fz[p]);
@@ -154,11 +161,11 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
   }
 
   if (gridDim.y == 1) {
+    const double g = UNIFORM ? (double)G * (double)ms[0] : (double)G;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       const int i = i0 + k * BLOCK;
       if (i < n_snk) {
-        const double g = (double)G;
         float ox = (float)(g * tx[k]), oy = (float)(g * ty[k]), oz = (float)(g * tz[k]);
         if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
         ax[i] = ox; ay[i] = oy; az[i] = oz;
@@ -176,7 +183,7 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
 
 // out[c][i] (+)= G * sum_s part[s][c][i], fixed summation order
 __global__ void __launch_bounds__(256)
-accel_reduce_f32_kernel(const double* __restrict__ part, int nsplit, int n_snk, float G,
+accel_reduce_f32_kernel(const double* __restrict__ part, int nsplit, int n_snk, float G, const float* __restrict__ m0,
                         float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_snk) return;
@@ -185,7 +192,7 @@ accel_reduce_f32_kernel(const double* __restrict__ part, int nsplit, int n_snk, 
     const double* p = part + (size_t)s * 3 * (size_t)n_snk;
     sx += p[i]; sy += p[(size_t)n_snk + i]; sz += p[2 * (size_t)n_snk + i];
   }
-  const double g = (double)G;
+  const double g = m0 ? (double)G * (double)m0[0] : (double)G;   // uniform-mass mode: common mass applied here
   float ox = (float)(g * sx), oy = (float)(g * sy), oz = (float)(g * sz);
   if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
   ax[i] = ox; ay[i] = oy; az[i] = oz;
@@ -197,23 +204,24 @@ int env_int(const char* name, int dflt) {
 }
 
 template <int KS, int U, int TILE>
-void launch_variant(bool guard, dim3 grid, hipStream_t st, const float* xi, const float* yi, const float* zi,
+void launch_variant(bool guard, bool uniform, dim3 grid, hipStream_t st, const float* xi, const float* yi, const float* zi,
                     int n_snk, const float* xs, const float* ys, const float* zs, const float* ms, int n_src,
                     int sps, float eps2, float G, float* ax, float* ay, float* az, double* part, int accumulate) {
-  if (guard)
-    accel_f32_kernel<KS, U, TILE, true><<<grid, BLOCK, 0, st>>>(xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps, eps2, G,
-                                                               ax, ay, az, part, accumulate);
-  else
-    accel_f32_kernel<KS, U, TILE, false><<<grid, BLOCK, 0, st>>>(xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps, eps2, G,
-                                                                ax, ay, az, part, accumulate);
+#define NB_LAUNCH(GD, UF) accel_f32_kernel<KS, U, TILE, GD, UF><<<grid, BLOCK, 0, st>>>( \
+    xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps, eps2, G, ax, ay, az, part, accumulate)
+  if (guard) { if (uniform) NB_LAUNCH(true, true); else NB_LAUNCH(true, false); }
+  else       { if (uniform) NB_LAUNCH(false, true); else NB_LAUNCH(false, false); }
+#undef NB_LAUNCH
 }
 
 }  // namespace
 
 int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, int64_t n_snk,
                         const float* xs, const float* ys, const float* zs, const float* ms, int64_t n_src,
-                        float eps2, float G, float* ax, float* ay, float* az, int accumulate) {
+                        float eps2, float G, float* ax, float* ay, float* az, int flags) {
   if (n_snk <= 0) return NB_OK;
+  const int accumulate = flags & NB_ACCUMULATE;
+  const bool uniform = (flags & NB_UNIFORM_MASS) && n_src > 0;
   if (n_snk >= (1ll << 31) || n_src >= (1ll << 31)) return nb_fail(c, NB_ERR_ARG, "n must be < 2^31");
   constexpr int TILE = 512;
   // sinks per lane: 8 (four packed pairs) as soon as there are enough sinks to fill lanes; measured on MI355X
@@ -245,24 +253,16 @@ int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float
   }
   const bool guard = !(eps2 >= 1e-20f);
   dim3 grid(nblk, nsplit);
-  int u = env_int("NB_F32_U", 0);
-  if (u != 1 && u != 2 && u != 4) u = 2;
-#define NB_GO(K, UU) launch_variant<K, UU, TILE>(guard, grid, c->stream, xi, yi, zi, (int)n_snk, xs, ys, zs, ms, (int)n_src, sps, eps2, G, ax, ay, az, part, accumulate)
-  switch (ks * 10 + u) {
-    case 21: NB_GO(2, 1); break;
-    case 22: NB_GO(2, 2); break;
-    case 24: NB_GO(2, 4); break;
-    case 41: NB_GO(4, 1); break;
-    case 42: NB_GO(4, 2); break;
-    case 44: NB_GO(4, 4); break;
-    case 81: NB_GO(8, 1); break;
-    case 82: NB_GO(8, 2); break;
-    default: NB_GO(8, 1); break;
+#define NB_GO(K, UU) launch_variant<K, UU, TILE>(guard, uniform, grid, c->stream, xi, yi, zi, (int)n_snk, xs, ys, zs, ms, (int)n_src, sps, eps2, G, ax, ay, az, part, accumulate)
+  switch (ks) {
+    case 2: NB_GO(2, 2); break;
+    case 4: NB_GO(4, 2); break;
+    default: NB_GO(8, 2); break;
   }
 #undef NB_GO
   NB_HIP(c, hipGetLastError());
   if (nsplit > 1) {
-    accel_reduce_f32_kernel<<<(int)((n_snk + 255) / 256), 256, 0, c->stream>>>(part, nsplit, (int)n_snk, G, ax, ay, az, accumulate);
+    accel_reduce_f32_kernel<<<(int)((n_snk + 255) / 256), 256, 0, c->stream>>>(part, nsplit, (int)n_snk, G, uniform ? ms : nullptr, ax, ay, az, accumulate);
     NB_HIP(c, hipGetLastError());
   }
   return NB_OK;

@@ -162,8 +162,9 @@ void launch_variant(bool guard, dim3 grid, hipStream_t st, const double* xi, con
 
 int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const double* zi, int64_t n_snk,
                         const double* xs, const double* ys, const double* zs, const double* ms, int64_t n_src,
-                        double eps2, double G, double* ax, double* ay, double* az, int accumulate) {
+                        double eps2, double G, double* ax, double* ay, double* az, int flags) {
   if (n_snk <= 0) return NB_OK;
+  const int accumulate = flags & NB_ACCUMULATE;   // NB_UNIFORM_MASS is a hint the fp64 kernel does not need
   if (n_snk >= (1ll << 31) || n_src >= (1ll << 31)) return nb_fail(c, NB_ERR_ARG, "n must be < 2^31");
   constexpr int TILE = 256;
   int ks = env_int("NB_F64_KS", 0);

@@ -14,6 +14,7 @@ struct nb_ctx {
   // SoA state, one allocation: [x y z m | vx vy vz | ax ay az], each of length n (element = float or double)
   void* state = nullptr;
   bool has_state = false;
+  bool uniform_mass = false;  // all masses given to nb_set_state were equal (checked on the host copy)
   bool acc_valid = false;     // ax,ay,az hold a(x) for the current positions and (eps, G) below
   double acc_eps = -1.0, acc_G = 0.0;
   // scratch: split-source partial sums and block-level reductions
@@ -40,10 +41,10 @@ int nb_ensure_work(nb_ctx* c, size_t bytes);
 // launchers (defined in the kernel translation units); all asynchronous on c->stream
 int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, int64_t n_snk,
                         const float* xs, const float* ys, const float* zs, const float* ms, int64_t n_src,
-                        float eps2, float G, float* ax, float* ay, float* az, int accumulate);
+                        float eps2, float G, float* ax, float* ay, float* az, int flags);
 int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const double* zi, int64_t n_snk,
                         const double* xs, const double* ys, const double* zs, const double* ms, int64_t n_src,
-                        double eps2, double G, double* ax, double* ay, double* az, int accumulate);
+                        double eps2, double G, double* ax, double* ay, double* az, int flags);
 int nb_launch_potential_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, const float* mi,
                             int64_t n_snk, int64_t snk_global0, const float* xs, const float* ys, const float* zs,
                             const float* ms, int64_t n_src, int64_t src_global0, float eps2, double* u_out,

@@ -81,13 +81,13 @@ class HipKernels:
         base = t.data_ptr()
         return [C.c_void_p(base + i * n * es) for i in range(k)]
 
-    def accel(self, snk, n_snk, src, n_src, eps, G, acc, accumulate):
+    def accel(self, snk, n_snk, src, n_src, eps, G, acc, accumulate, uniform_mass=False):
         self._bind()
         xi, yi, zi = self._rows(snk, 3)
         xs, ys, zs, ms = self._rows(src, 4)
         ax, ay, az = self._rows(acc, 3)
         rc = self._lib.nb_accel_dev(self._ctx, self._code(snk), xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, eps, G,
-                                    ax, ay, az, int(bool(accumulate)))
+                                    ax, ay, az, (_lib.NB_ACCUMULATE if accumulate else 0) | (_lib.NB_UNIFORM_MASS if uniform_mass else 0))
         _lib.check(self._ctx, rc, "nb_accel_dev")
 
     def potential(self, snk, n_snk, snk_g0, src, n_src, src_g0, eps, out, accumulate):
@@ -155,6 +155,7 @@ class ShardedEngine:
         self.gathered = z(self.world, 4, self.n_max) if (self.world > 1 and mode == "allgather") else None
         self.scal = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._acc_key = None
+        self.uniform_mass = False
         self.kernel_timer = None   # optional object with begin()/end(interactions): brackets every accel launch
 
     # -- state ----------------------------------------------------------------------------------
@@ -169,6 +170,9 @@ class ShardedEngine:
         pm[3, : self.n_loc] = np.asarray(state.mass)[s]
         vel = np.zeros((3, self.n_max), self.np_dtype)
         vel[:, : self.n_loc] = np.asarray(state.vel)[s].T
+        # equal masses everywhere (checked on the global host copy, identical on every rank): cheaper inner loop
+        m_all = np.asarray(state.mass)
+        self.uniform_mass = bool(m_all.size > 0 and np.all(m_all == m_all.flat[0]))
         self.pm.copy_(t.from_numpy(pm))
         self.vel.copy_(t.from_numpy(vel))
         self._acc_key = None
@@ -230,7 +234,7 @@ class ShardedEngine:
         def one(src, owner, first):
             if tm is not None:
                 tm.begin()
-            self.k.accel(self.pm, self.n_loc, src, self.counts[owner], eps, G, self.acc, not first)
+            self.k.accel(self.pm, self.n_loc, src, self.counts[owner], eps, G, self.acc, not first, self.uniform_mass)
             if tm is not None:
                 tm.end(float(self.n_loc) * float(self.counts[owner]))
         self._for_each_chunk(one)

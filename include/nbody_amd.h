@@ -35,6 +35,11 @@ extern "C" {
 typedef struct nb_ctx nb_ctx;
 
 enum { NB_F32 = 0, NB_F64 = 1 };
+/* flags of nb_accel_dev */
+enum {
+  NB_ACCUMULATE = 1,   /* add to the existing ax/ay/az instead of overwriting (source chunks arriving hop by hop) */
+  NB_UNIFORM_MASS = 2  /* the caller guarantees all n_src source masses equal ms[0]: enables the 11-op inner loop */
+};
 enum {
   NB_OK = 0,
   NB_ERR_ARG = -1,      /* bad argument (null pointer, n <= 0, unknown dtype ...) */
@@ -72,11 +77,11 @@ int nb_energy(nb_ctx* ctx, double eps, double G, double* kinetic, double* potent
 
 /* ---- device-pointer surface: building blocks for the sink-decomposed multi-GPU path ---- */
 /* acc[i] (+)= G * sum_{j<n_src} m_j (r_j - r_i)/(r_ij^2+eps^2)^{3/2} for i < n_snk.
- * accumulate != 0 adds to the existing ax/ay/az (used when source chunks arrive one ring hop at a time). */
+ * flags: NB_ACCUMULATE | NB_UNIFORM_MASS (see above). */
 int nb_accel_dev(nb_ctx* ctx, int dtype,
                  const void* xi, const void* yi, const void* zi, int64_t n_snk,
                  const void* xs, const void* ys, const void* zs, const void* ms, int64_t n_src,
-                 double eps, double G, void* ax, void* ay, void* az, int accumulate);
+                 double eps, double G, void* ax, void* ay, void* az, int flags);
 /* u_out[0] (+)= sum_i m_i sum_{j != i (by global index)} m_j / sqrt(r_ij^2+eps^2)   (device double;
  * the caller applies -G/2). snk_global0 / src_global0 are the global indices of element 0 of each set. */
 int nb_potential_dev(nb_ctx* ctx, int dtype,

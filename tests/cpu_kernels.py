@@ -8,7 +8,7 @@ from oracle import nbody_oracle as ora
 
 
 class OracleKernels:
-    def accel(self, snk, n_snk, src, n_src, eps, G, acc, accumulate):
+    def accel(self, snk, n_snk, src, n_src, eps, G, acc, accumulate, uniform_mass=False):
         s, q = snk.numpy(), src.numpy()
         a = ora.compute_forces(q[:3, :n_src].T, q[3, :n_src], eps, G, sinks=s[:3, :n_snk].T).T
         out = acc.numpy()

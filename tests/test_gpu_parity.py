@@ -268,3 +268,32 @@ def test_graph_replayed_steps_equal_eager_steps(dtype, monkeypatch):
         ref = e.get_state()
     np.testing.assert_array_equal(g.pos, ref.pos)
     np.testing.assert_array_equal(g.vel, ref.vel)
+
+
+# ------------------------------------------------------------------ uniform-mass fast path
+def test_uniform_mass_flag_matches_general_path():
+    """NB_UNIFORM_MASS drops the per-source mass multiply; with equal masses it must agree with the general kernel
+    (and the oracle), for ragged source counts (padding sources sit at 1e18), accumulation and eps = 0."""
+    import torch
+    s = nb.plummer_sphere(4321, 29, np.float32)
+    k = nb.HipKernels(0)
+    pm = torch.from_numpy(np.vstack([s.pos.T, s.mass[None, :]])).contiguous().cuda()
+    for eps in (0.01, 0.0):
+        gen = torch.empty(3, s.n, device="cuda")
+        uni = torch.empty(3, s.n, device="cuda")
+        k.accel(pm, s.n, pm, s.n, eps, 2.5, gen, False, False)
+        k.accel(pm, s.n, pm[:, :1000].contiguous(), 1000, eps, 2.5, uni, False, True)
+        k.accel(pm, s.n, pm[:, 1000:].contiguous(), s.n - 1000, eps, 2.5, uni, True, True)
+        torch.cuda.synchronize()
+        ref = ora.compute_forces(s.pos.astype(np.float64), s.mass.astype(np.float64), eps, 2.5)
+        assert rel_err(uni.cpu().numpy().T, ref).max() < TOL[np.float32]
+        assert rel_err(gen.cpu().numpy().T, ref).max() < TOL[np.float32]
+
+
+def test_engine_detects_uniform_and_nonuniform_masses():
+    s = nb.plummer_sphere(3000, 31, np.float32)
+    a_uni = nb.compute_forces(s.pos, s.mass, 0.01)                    # equal masses -> uniform kernel
+    m2 = s.mass.copy(); m2[1234] *= 1.0000001                         # one different mass -> general kernel
+    a_gen = nb.compute_forces(s.pos, m2, 0.01)
+    assert rel_err(a_uni, ora.compute_forces(s.pos.astype(np.float64), s.mass.astype(np.float64), 0.01)).max() < TOL[np.float32]
+    assert rel_err(a_gen, ora.compute_forces(s.pos.astype(np.float64), m2.astype(np.float64), 0.01)).max() < TOL[np.float32]
