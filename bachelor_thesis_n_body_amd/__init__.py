@@ -17,8 +17,8 @@ from .state import State
 from .ics import plummer_sphere, PLUMMER_A
 from .api import Engine, compute_forces, step, energy
 from .dist import ShardedEngine, HipKernels, partition
-from . import field, snapshot
+from . import field, grf, snapshot
 
 __all__ = ["State", "plummer_sphere", "PLUMMER_A", "Engine", "compute_forces", "step", "energy",
-           "ShardedEngine", "HipKernels", "partition", "field", "snapshot"]
+           "ShardedEngine", "HipKernels", "partition", "field", "grf", "snapshot"]
 __version__ = "0.1.0"

@@ -33,6 +33,11 @@ struct nbf_plan {
   double* pos = nullptr;             // device staging for positions
   size_t pos_cap = 0;
   double* part = nullptr;            // reduction partials
+  hipfftDoubleComplex* noise = nullptr;   // [ngrid^3] Hermitian-symmetrised R (GRF generator)
+  double* amp = nullptr;             // [ngrid^3] sqrt(P)*fac
+  double* stage2 = nullptr;          // [2*ngrid^3] upload staging for c1, c2
+  double* zpos = nullptr;            // [ngrid^3 * 3] Zel'dovich positions
+  bool have_noise = false, have_amp = false;
   hipfftHandle fft = 0;
   bool have_fft = false;
   hipStream_t stream = nullptr;
@@ -185,6 +190,57 @@ power_bin_kernel(const hipfftDoubleComplex* __restrict__ c, const double* __rest
   }
 }
 
+// R = c1 + i c2 made Hermitian exactly as the reference's lexicographic triple loop leaves it: the member of a mirror
+// pair visited first keeps its value, the other becomes its conjugate; a self-conjugate point is conjugated once
+// (variant 0) or untouched (variant 1); R[0,0,0] is real.
+__global__ void __launch_bounds__(256)
+hermitian_kernel(const double* __restrict__ c1, const double* __restrict__ c2, hipfftDoubleComplex* __restrict__ R,
+                 int N, int variant) {
+  const size_t n = (size_t)N * N * N;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % N), j = (int)((idx / N) % N), i = (int)(idx / ((size_t)N * N));
+    const int mi = (N - i) % N, mj = (N - j) % N, mk = (N - k) % N;
+    const size_t m = ((size_t)mi * N + mj) * N + mk;
+    double re, im;
+    if (idx > m) { re = c1[m]; im = -c2[m]; if (m == 0) im = -0.0; }        // conj(original mirror); mirror 0 is real
+    else if (idx == m) { re = c1[idx]; im = variant == 0 ? -c2[idx] : c2[idx]; if (idx == 0) im = variant == 0 ? -0.0 : 0.0; }
+    else { re = c1[idx]; im = c2[idx]; }
+    R[idx].x = re; R[idx].y = im;
+  }
+}
+
+// cgrid = (amp * mult) * R with mult = 1 (component 0) or i*k_c/|k|^2 (components 1..3), NumPy's evaluation order:
+// ((1j*kc) / k_mag**2) * delta_k, then complex * complex with a zero real part.
+__global__ void __launch_bounds__(256)
+grf_product_kernel(const hipfftDoubleComplex* __restrict__ R, const double* __restrict__ amp, const double* __restrict__ kv,
+                   hipfftDoubleComplex* __restrict__ out, int N, int comp) {
+  const size_t n = (size_t)N * N * N;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const double rr = R[idx].x, ri = R[idx].y, a = amp[idx];
+    if (comp == 0) { out[idx].x = a * rr; out[idx].y = a * ri; continue; }
+    const int k = (int)(idx % N), j = (int)((idx / N) % N), i = (int)(idx / ((size_t)N * N));
+    const double kx = kv[i], ky = kv[j], kz = kv[k];
+    double km = sqrt((kx * kx + ky * ky) + kz * kz);
+    if (idx == 0) km = 1e-10;
+    const double kc = comp == 1 ? kx : (comp == 2 ? ky : kz);
+    const double b = (kc / (km * km)) * a;          // psi_k = 0 + i*b
+    out[idx].x = 0.0 * rr - b * ri;
+    out[idx].y = 0.0 * ri + b * rr;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+zeldovich_kernel(const double* __restrict__ psi, double* __restrict__ pos, int N, double L, int comp) {
+  const size_t n = (size_t)N * N * N;
+  const double step = L / N;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % N), j = (int)((idx / N) % N), i = (int)(idx / ((size_t)N * N));
+    const int c = comp == 0 ? i : (comp == 1 ? j : k);
+    const double x = (double)c * step + psi[idx];       // np.linspace(0, L, N, endpoint=False)[c] + displacement
+    pos[3 * idx + comp] = py_mod(x, L);
+  }
+}
+
 inline int grid_for(size_t n) {
   size_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -240,7 +296,8 @@ int nbf_destroy(nbf_plan* p) {
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   if (p->have_fft) (void)hipfftDestroy(p->fft);
-  void* bufs[] = {p->grid, p->cgrid, p->w1d, p->kvals, p->edges, p->psum, p->counts, p->pos, p->part};
+  void* bufs[] = {p->grid, p->cgrid, p->w1d, p->kvals, p->edges, p->psum, p->counts, p->pos, p->part,
+                  p->noise, p->amp, p->stage2, p->zpos};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
@@ -363,6 +420,69 @@ int nbf_power_bins(nbf_plan* p, double scale, double* psum, int64_t* counts) {
   F_HIP(p, hipMemcpyAsync(psum, p->psum, nb * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   static_assert(sizeof(unsigned long long) == sizeof(int64_t), "count type");
   F_HIP(p, hipMemcpyAsync(counts, p->counts, nb * sizeof(int64_t), hipMemcpyDeviceToHost, p->stream));
+  F_HIP(p, hipStreamSynchronize(p->stream));
+  return NB_OK;
+}
+
+int nbf_noise_hermitian(nbf_plan* p, const double* c1, const double* c2, int variant) {
+  if (!p || !c1 || !c2) return ffail(p, NB_ERR_ARG, "nbf_noise_hermitian: NULL argument");
+  if (variant != 0 && variant != 1) return ffail(p, NB_ERR_ARG, "nbf_noise_hermitian: variant must be 0 or 1");
+  int rc = use_dev(p); if (rc) return rc;
+  const size_t b = p->cells * sizeof(double);
+  if (!p->stage2) F_HIP(p, hipMalloc((void**)&p->stage2, 2 * b));
+  if (!p->noise) F_HIP(p, hipMalloc((void**)&p->noise, p->cells * sizeof(hipfftDoubleComplex)));
+  F_HIP(p, hipMemcpyAsync(p->stage2, c1, b, hipMemcpyHostToDevice, p->stream));
+  F_HIP(p, hipMemcpyAsync(p->stage2 + p->cells, c2, b, hipMemcpyHostToDevice, p->stream));
+  hermitian_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->stage2, p->stage2 + p->cells, p->noise, p->ngrid, variant);
+  F_HIP(p, hipGetLastError());
+  F_HIP(p, hipStreamSynchronize(p->stream));
+  p->have_noise = true;
+  return NB_OK;
+}
+
+int nbf_get_noise(nbf_plan* p, double* out) {
+  if (!p || !out) return ffail(p, NB_ERR_ARG, "nbf_get_noise: NULL argument");
+  if (!p->have_noise) return ffail(p, NB_ERR_STATE, "nbf_get_noise: call nbf_noise_hermitian first");
+  int rc = use_dev(p); if (rc) return rc;
+  F_HIP(p, hipMemcpyAsync(out, p->noise, p->cells * sizeof(hipfftDoubleComplex), hipMemcpyDeviceToHost, p->stream));
+  F_HIP(p, hipStreamSynchronize(p->stream));
+  return NB_OK;
+}
+
+int nbf_set_amplitude(nbf_plan* p, const double* amp, const double* kvals) {
+  if (!p || !amp || !kvals) return ffail(p, NB_ERR_ARG, "nbf_set_amplitude: NULL argument");
+  int rc = use_dev(p); if (rc) return rc;
+  if (!p->amp) F_HIP(p, hipMalloc((void**)&p->amp, p->cells * sizeof(double)));
+  F_HIP(p, hipMemcpyAsync(p->amp, amp, p->cells * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  F_HIP(p, hipMemcpyAsync(p->kvals, kvals, p->ngrid * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  F_HIP(p, hipStreamSynchronize(p->stream));
+  p->have_amp = true;
+  return NB_OK;
+}
+
+int nbf_grf_field(nbf_plan* p, int component) {
+  if (!p) return NB_ERR_ARG;
+  if (component < 0 || component > 3) return ffail(p, NB_ERR_ARG, "nbf_grf_field: component must be 0..3");
+  if (!p->have_noise || !p->have_amp) return ffail(p, NB_ERR_STATE, "nbf_grf_field: set the noise and the amplitude first");
+  int rc = use_dev(p); if (rc) return rc;
+  grf_product_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->noise, p->amp, p->kvals, p->cgrid, p->ngrid, component);
+  F_HIP(p, hipGetLastError());
+  F_FFT(p, hipfftExecZ2Z(p->fft, p->cgrid, p->cgrid, HIPFFT_BACKWARD));
+  c2r_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->cgrid, p->grid, p->cells, 1.0 / (double)p->cells);
+  F_HIP(p, hipGetLastError());
+  return NB_OK;
+}
+
+int nbf_zeldovich(nbf_plan* p, double* pos_out) {
+  if (!p || !pos_out) return ffail(p, NB_ERR_ARG, "nbf_zeldovich: NULL argument");
+  int rc = use_dev(p); if (rc) return rc;
+  if (!p->zpos) F_HIP(p, hipMalloc((void**)&p->zpos, p->cells * 3 * sizeof(double)));
+  for (int comp = 0; comp < 3; ++comp) {
+    rc = nbf_grf_field(p, comp + 1); if (rc) return rc;
+    zeldovich_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->grid, p->zpos, p->ngrid, p->boxsize, comp);
+    F_HIP(p, hipGetLastError());
+  }
+  F_HIP(p, hipMemcpyAsync(pos_out, p->zpos, p->cells * 3 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   F_HIP(p, hipStreamSynchronize(p->stream));
   return NB_OK;
 }

@@ -46,6 +46,24 @@ int nbf_set_grid(nbf_plan* plan, const double* in);
 /* psum[nedges-1], counts[nedges-1] <- histogram over all modes of |fftn(grid)|^2 * scale, binned by |k| */
 int nbf_power_bins(nbf_plan* plan, double scale, double* psum, int64_t* counts);
 
+/* ---- Gaussian-random-field + Zel'dovich initial conditions --------------------------------
+ * Replaces the O(N^3) Python triple loop createR (TheFeedingPipeline/Cosmo data create (new).py:24-47,
+ * CiC/3D startbetingelser1.py:82-94) and the field synthesis around it (Cosmo data create (new).py:129-135,
+ * CiC/3D startbetingelser1.py:98-112, 119-173). The Gaussian draws c1, c2 and the amplitude grid sqrt(P(k))*fac are
+ * host inputs (the reference's RNG and CLASS stay on the host); everything O(ngrid^3) runs on the GPU. */
+/* R <- Hermitian-symmetrised c1 + i*c2 (host arrays, ngrid^3 each). variant 0: self-conjugate points are replaced
+ * by their own conjugate (Cosmo data create (new).py:39-45); variant 1: they are left alone (3D startbetingelser1.py:86-94) */
+int nbf_noise_hermitian(nbf_plan* plan, const double* c1, const double* c2, int variant);
+/* copy R out as interleaved (re, im) doubles, 2*ngrid^3 */
+int nbf_get_noise(nbf_plan* plan, double* out_re_im);
+/* amplitude grid delta_k = sqrt(P_k_grid) * fac (host, ngrid^3) and the k values along one axis (host, ngrid) */
+int nbf_set_amplitude(nbf_plan* plan, const double* amp, const double* kvals);
+/* grid <- real(ifftn(amp * mult * R)); component 0: delta (mult = 1); 1/2/3: psi_x/y/z (mult = i k_c / |k|^2,
+ * |k| at [0,0,0] replaced by 1e-10 as in the reference) */
+int nbf_grf_field(nbf_plan* plan, int component);
+/* pos_out[(ngrid^3),3] <- (lattice + psi) mod L, lattice = i*L/ngrid on every axis (host output) */
+int nbf_zeldovich(nbf_plan* plan, double* pos_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,7 +37,8 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 10
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/nbody_field.h but not exported"
-    assert sorted(field.FIELD_SIGNATURES) == names
+    from bachelor_thesis_n_body_amd import grf
+    assert sorted(list(field.FIELD_SIGNATURES) + list(grf.GRF_SIGNATURES)) == names
 
 
 def test_abi_is_plain_c():
