@@ -78,7 +78,10 @@ int nb_create(nb_ctx** out, int64_t n, int dtype, int device) {
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
   c->own_stream = true;
   if ((e = hipMalloc(&c->state, (size_t)10 * (size_t)n * esize(dtype))) != hipSuccess) return bail("hipMalloc(state)", e);
-  if ((e = hipMemset(c->state, 0, (size_t)10 * (size_t)n * esize(dtype))) != hipSuccess) return bail("hipMemset(state)", e);
+  // zero on the context's own stream: a plain hipMemset runs on the NULL stream, which a non-blocking stream does
+  // not order against, so it could land AFTER the first nb_set_state copies (seen once as garbage accelerations)
+  if ((e = hipMemsetAsync(c->state, 0, (size_t)10 * (size_t)n * esize(dtype), c->stream)) != hipSuccess) return bail("hipMemsetAsync(state)", e);
+  if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("hipStreamSynchronize", e);
   if ((e = hipMalloc((void**)&c->scal, 8 * sizeof(double))) != hipSuccess) return bail("hipMalloc(scalars)", e);
   *out = c;
   return NB_OK;

@@ -282,7 +282,9 @@ int nbf_create(nbf_plan** out, int ngrid, double boxsize, int device) {
   if ((e = hipMalloc((void**)&p->w1d, ngrid * sizeof(double))) != hipSuccess) return bail("hipMalloc(w1d) failed");
   if ((e = hipMalloc((void**)&p->kvals, ngrid * sizeof(double))) != hipSuccess) return bail("hipMalloc(kvals) failed");
   if ((e = hipMalloc((void**)&p->part, 4096 * sizeof(double))) != hipSuccess) return bail("hipMalloc(part) failed");
-  if ((e = hipMemset(p->grid, 0, p->cells * sizeof(double))) != hipSuccess) return bail("hipMemset failed");
+  // on the plan's own (non-blocking) stream, not the NULL stream: later work on p->stream must be ordered after it
+  if ((e = hipMemsetAsync(p->grid, 0, p->cells * sizeof(double), p->stream)) != hipSuccess) return bail("hipMemsetAsync failed");
+  if ((e = hipStreamSynchronize(p->stream)) != hipSuccess) return bail("hipStreamSynchronize failed");
   hipfftResult r = hipfftPlan3d(&p->fft, ngrid, ngrid, ngrid, HIPFFT_Z2Z);
   if (r != HIPFFT_SUCCESS) return bail("hipfftPlan3d failed: " + std::to_string((int)r));
   p->have_fft = true;
