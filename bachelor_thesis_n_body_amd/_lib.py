@@ -12,6 +12,7 @@ from pathlib import Path
 NB_F32, NB_F64 = 0, 1
 NB_OK = 0
 NB_ACCUMULATE, NB_UNIFORM_MASS = 1, 2
+NB_SOLVER_DIRECT, NB_SOLVER_TREE = 0, 1
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libnbody_amd.so"
@@ -26,6 +27,7 @@ SIGNATURES = {
     "nb_destroy": (_int, [_vp]),
     "nb_set_stream": (_int, [_vp, _vp]),
     "nb_synchronize": (_int, [_vp]),
+    "nb_set_solver": (_int, [_vp, _int, _dbl]),
     "nb_set_state": (_int, [_vp] + [_vp] * 7),
     "nb_get_state": (_int, [_vp] + [_vp] * 7),
     "nb_accel": (_int, [_vp, _dbl, _dbl, _vp, _vp, _vp]),

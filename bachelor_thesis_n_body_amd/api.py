@@ -67,6 +67,11 @@ class Engine:
     def set_stream(self, hip_stream: int) -> None:
         _lib.check(self._ctx, self._lib.nb_set_stream(self._ctx, C.c_void_p(hip_stream)), "nb_set_stream")
 
+    def set_solver(self, method: str = "direct", theta: float = 0.5) -> None:
+        """'direct' = O(N^2) summation (default); 'tree' = Barnes-Hut with opening angle theta (fp32 engines only)."""
+        code = {"direct": _lib.NB_SOLVER_DIRECT, "tree": _lib.NB_SOLVER_TREE}[method]
+        _lib.check(self._ctx, self._lib.nb_set_solver(self._ctx, code, float(theta)), "nb_set_solver")
+
     def synchronize(self) -> None:
         _lib.check(self._ctx, self._lib.nb_synchronize(self._ctx), "nb_synchronize")
 
@@ -127,15 +132,19 @@ def _infer_dtype(a, dtype):
     return d if d in _DT else np.dtype(np.float64)
 
 
-def compute_forces(pos, mass, eps: float, G: float = 1.0, dtype=None, device: int = 0) -> np.ndarray:
+def compute_forces(pos, mass, eps: float, G: float = 1.0, dtype=None, device: int = 0, method: str = "direct",
+                   theta: float = 0.5) -> np.ndarray:
     """Softened all-pairs acceleration a_i = G sum_j m_j (r_j-r_i)/(r_ij^2+eps^2)^{3/2} on the GPU.
-    `dtype` defaults to the dtype of `pos` (float32 -> fp32 kernel, anything else -> fp64 kernel)."""
+    `dtype` defaults to the dtype of `pos` (float32 -> fp32 kernel, anything else -> fp64 kernel).
+    method="tree" evaluates the sum with the Barnes-Hut tree (opening angle `theta`, fp32 only)."""
     pos = np.asarray(pos)
     dt = _infer_dtype(pos, dtype)
     n = pos.shape[0]
     if n == 0:
         return np.zeros((0, 3), dt)
     with Engine(n, dt, device) as e:
+        if method != "direct":
+            e.set_solver(method, theta)
         e.set_state(State(pos, np.zeros_like(pos), np.asarray(mass)))
         return e.accel(eps, G)
 

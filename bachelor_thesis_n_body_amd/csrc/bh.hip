@@ -1,0 +1,335 @@
+// Barnes-Hut tree gravity for gfx950 (BASELINE.json configs[4]: theta = 0.5, N = 16M, one MI355X, fp32).
+//
+// The reference contains no tree code; the algorithm is fixed here and restated sequentially in
+// oracle/bh_oracle.c so that the GPU result can be checked node for node:
+//   1. bounding cube of all particles; 63-bit Morton key per particle (21 bits per axis)        [morton_kernel]
+//   2. radix sort of (key, index) pairs (rocPRIM), gather to sorted (x,y,z,m) float4               [gather_kernel]
+//   3. binary radix tree over the sorted keys (Karras 2012): internal node i in [0, n-1), leaf j = node n-1+j; every
+//      node covers a CONTIGUOUS range of the sorted particles                                      [build_kernel]
+//   4. node mass / centre of mass from fp64 prefix sums of m, m*x, m*y, m*z over the sorted order (no bottom-up
+//      pass, no inter-workgroup hand-off); node size l = edge of the Morton cell of the node's common prefix
+//                                                                                                  [node_kernel]
+//   5. traversal: one 64-lane wave per group of 64 consecutive sorted particles, one depth-first walk per wave with a
+//      wave-shared stack in LDS; a node is accepted when l^2 < theta^2 d^2 holds for EVERY lane of the wave
+//      (__all = wave ballot), d = distance lane particle -> node centre of mass; rejected nodes with <= NLEAF particles
+//      are summed directly, others push their two children. Node data and leaf particles are read with wave-uniform
+//      addresses. Accepted nodes interact as monopoles: a += G m_node d / (d^2 + eps^2)^{3/2}.    [walk_kernel]
+// Irregular, latency/issue bound (not a roofline kernel): measured numbers are in DESIGN.md.
+#include "nb_common.h"
+#include "../../include/nbody_amd.h"
+#include <cstring>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+constexpr int NLEAF = 16;          // a rejected node with at most this many particles is summed directly
+constexpr int STACK = 192;         // per-wave stack entries (binary tree depth <= 63 key bits + 32 index bits)
+
+struct BHBuf {
+  float* bbox = nullptr;                     // 6 floats: min xyz, max xyz ; then [6] = cube edge
+  unsigned long long *keys = nullptr, *keys_sorted = nullptr;
+  int *idx = nullptr, *idx_sorted = nullptr;
+  float4* sp = nullptr;                      // sorted (x,y,z,m)
+  double* pre = nullptr;                     // 4 prefix arrays [4][n] (m, mx, my, mz), inclusive
+  int2* child = nullptr;                     // internal nodes: (left, right) node ids
+  int2* range = nullptr;                     // all nodes: (first, count)
+  float4* com = nullptr;                     // all nodes: (cx, cy, cz, mass)
+  float* l2 = nullptr;                       // all nodes: cell edge squared
+  float* out = nullptr;                      // [3][n] accelerations in sorted order
+  void* tmp = nullptr; size_t tmp_bytes = 0; // rocPRIM scratch
+  int64_t cap = 0;
+};
+
+__device__ inline unsigned long long spread21(unsigned int v) {
+  unsigned long long x = v & 0x1fffffull;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+
+__global__ void __launch_bounds__(256)
+bbox_partial_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
+                    float* __restrict__ part) {
+  float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float v[3] = {x[i], y[i], z[i]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], v[c]); hi[c] = fmaxf(hi[c], v[c]); }
+  }
+  __shared__ float red[6][256];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { red[c][threadIdx.x] = lo[c]; red[3 + c][threadIdx.x] = hi[c]; }
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        red[c][threadIdx.x] = fminf(red[c][threadIdx.x], red[c][threadIdx.x + w]);
+        red[3 + c][threadIdx.x] = fmaxf(red[3 + c][threadIdx.x], red[3 + c][threadIdx.x + w]);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, float* __restrict__ bbox) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int b = 0; b < nparts; ++b)
+      for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], part[b * 6 + c]); hi[c] = fmaxf(hi[c], part[b * 6 + 3 + c]); }
+    float edge = fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));
+    edge = edge > 0.f ? edge * 1.0001f : 1.0f;       // strictly inside the cube; a single point gets a unit cube
+    for (int c = 0; c < 3; ++c) { bbox[c] = lo[c]; bbox[3 + c] = hi[c]; }
+    bbox[6] = edge;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+morton_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
+              const float* __restrict__ bbox, unsigned long long* __restrict__ keys, int* __restrict__ idx) {
+  const float edge = bbox[6];
+  const float scale = 2097152.0f / edge;   // 2^21 cells per axis
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    unsigned int q[3];
+    const float v[3] = {x[i], y[i], z[i]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float t = (v[c] - bbox[c]) * scale;
+      t = fminf(fmaxf(t, 0.0f), 2097151.0f);
+      q[c] = (unsigned int)t;
+    }
+    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    idx[i] = i;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gather_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+              const float* __restrict__ m, const int* __restrict__ idx, int n, float4* __restrict__ sp,
+              double* __restrict__ pre) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int j = idx[i];
+    const float4 p = make_float4(x[j], y[j], z[j], m[j]);
+    sp[i] = p;
+    const double mm = (double)p.w;
+    pre[i] = mm; pre[(size_t)n + i] = mm * (double)p.x; pre[2 * (size_t)n + i] = mm * (double)p.y; pre[3 * (size_t)n + i] = mm * (double)p.z;
+  }
+}
+
+// length of the common prefix of the (key, position) strings of sorted elements i and j; -1 outside [0, n)
+__device__ inline int delta(const unsigned long long* __restrict__ k, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const unsigned long long a = k[i], b = k[j];
+  if (a != b) return __clzll(a ^ b);
+  return 64 + __clz((unsigned int)i ^ (unsigned int)j);
+}
+
+// Karras (2012) binary radix tree: internal node i covers the sorted range [first, last]; children are internal
+// nodes or leaves (leaf j has node id n-1+j).
+__global__ void __launch_bounds__(256)
+build_kernel(const unsigned long long* __restrict__ k, int n, int2* __restrict__ child, int2* __restrict__ range,
+             float* __restrict__ l2, const float* __restrict__ bbox) {
+  const float edge = bbox[6];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n - 1; i += gridDim.x * blockDim.x) {
+    const int d = delta(k, n, i, i + 1) - delta(k, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = delta(k, n, i, i - d);
+    int lmax = 2;
+    while (delta(k, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+      if (delta(k, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(k, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+      if (delta(k, n, i, i + (s + t) * d) > dnode) s += t;
+      if (t == 1) break;
+    }
+    const int gamma = i + s * d + min(d, 0);
+    const int first = min(i, j), last = max(i, j);
+    const int left = (first == gamma) ? (n - 1 + gamma) : gamma;
+    const int right = (last == gamma + 1) ? (n - 1 + gamma + 1) : (gamma + 1);
+    child[i] = make_int2(left, right);
+    range[i] = make_int2(first, last - first + 1);
+    // Morton cell of the common key prefix: level = prefix bits / 3 (the key's top bit is unused: 63 = 3*21 bits)
+    const int pbits = dnode >= 64 ? 63 : max(dnode - 1, 0);
+    const int level = pbits / 3;
+    const float cell = ldexpf(edge, -level);
+    l2[i] = cell * cell;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+node_kernel(const double* __restrict__ pre, const float4* __restrict__ sp, int n, int2* __restrict__ range,
+            float4* __restrict__ com, float* __restrict__ l2) {
+  const int total = 2 * n - 1;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+    if (v >= n - 1) {                       // leaf
+      const int j = v - (n - 1);
+      range[v] = make_int2(j, 1);
+      com[v] = sp[j];
+      l2[v] = 0.0f;
+      continue;
+    }
+    const int2 r = range[v];
+    const int a = r.x, b = r.x + r.y - 1;
+    double s[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[c] = pre[(size_t)c * n + b] - (a > 0 ? pre[(size_t)c * n + a - 1] : 0.0);
+    float4 o;
+    if (s[0] > 0.0) o = make_float4((float)(s[1] / s[0]), (float)(s[2] / s[0]), (float)(s[3] / s[0]), (float)s[0]);
+    else {                                  // massless range: geometric anchor = first particle, mass 0
+      const float4 p = sp[a];
+      o = make_float4(p.x, p.y, p.z, 0.0f);
+    }
+    com[v] = o;
+  }
+}
+
+template <bool GUARD>
+__global__ void __launch_bounds__(256)
+walk_kernel(const float4* __restrict__ sp, int n, const int2* __restrict__ child, const int2* __restrict__ range,
+            const float4* __restrict__ com, const float* __restrict__ l2, float theta2, float eps2,
+            float* __restrict__ out) {
+  __shared__ int stack_all[4][STACK];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  volatile int* stack = stack_all[wave];
+  const int group = blockIdx.x * 4 + wave;
+  const int i = group * 64 + lane;
+  const bool live = i < n;
+  const float4 me = sp[live ? i : n - 1];
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  if (group * 64 >= n) return;              // whole wave out of range (wave-uniform)
+
+  int sp_top = 0;
+  if (lane == 0) stack[0] = 0;              // root = internal node 0 (n >= 2 guaranteed by the launcher)
+  sp_top = 1;
+  while (sp_top > 0) {
+    const int v = __builtin_amdgcn_readfirstlane(stack[sp_top - 1]);
+    --sp_top;
+    const float4 c = com[v];
+    const float dx = c.x - me.x, dy = c.y - me.y, dz = c.z - me.z;
+    const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));   // same expression as oracle/bh_oracle.c: identical MAC decisions
+    const int2 r = range[v];
+    const bool is_leaf = v >= n - 1;
+    // accept (all lanes): cell small enough seen from every particle of the group; padding lanes vote yes
+    const bool ok = is_leaf ? true : (!live || l2[v] < theta2 * d2);
+    if (!is_leaf && __all(ok)) {
+      const float r2 = d2 + eps2;
+      float rinv = __builtin_amdgcn_rsqf(r2);
+      if (GUARD) rinv = r2 > 0.f ? rinv : 0.f;
+      const float f = c.w * rinv * rinv * rinv;
+      ax = fmaf(f, dx, ax); ay = fmaf(f, dy, ay); az = fmaf(f, dz, az);
+    } else if (is_leaf || r.y <= NLEAF) {
+      for (int j = r.x; j < r.x + r.y; ++j) {
+        const float4 q = sp[j];                            // wave-uniform address
+        const float ex = q.x - me.x, ey = q.y - me.y, ez = q.z - me.z;
+        const float r2 = fmaf(ex, ex, fmaf(ey, ey, ez * ez)) + eps2;
+        float rinv = __builtin_amdgcn_rsqf(r2);
+        if (GUARD) rinv = r2 > 0.f ? rinv : 0.f;           // the particle itself / coincident pairs at eps = 0
+        const float f = q.w * rinv * rinv * rinv;
+        ax = fmaf(f, ex, ax); ay = fmaf(f, ey, ay); az = fmaf(f, ez, az);
+      }
+    } else {
+      const int2 ch = child[v];
+      if (sp_top + 2 <= STACK) {
+        if (lane == 0) { stack[sp_top] = ch.y; stack[sp_top + 1] = ch.x; }   // left child is popped first
+        sp_top += 2;
+      }
+    }
+  }
+  if (live) { out[i] = ax; out[(size_t)n + i] = ay; out[2 * (size_t)n + i] = az; }
+}
+
+__global__ void __launch_bounds__(256)
+scatter_kernel(const float* __restrict__ sorted_out, const int* __restrict__ idx, int n, float G,
+               float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int j = idx[i];
+    ax[j] = G * sorted_out[i]; ay[j] = G * sorted_out[(size_t)n + i]; az[j] = G * sorted_out[2 * (size_t)n + i];
+  }
+}
+
+inline int grid_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+struct nb_bh_state { BHBuf b; };
+
+static void bh_free(BHBuf& b) {
+  void* p[] = {b.bbox, b.keys, b.keys_sorted, b.idx, b.idx_sorted, b.sp, b.pre, b.child, b.range, b.com, b.l2, b.out, b.tmp};
+  for (void* q : p) if (q) (void)hipFree(q);
+  b = BHBuf();
+}
+
+void nb_bh_release(nb_ctx* c) {
+  if (c->bh) { bh_free(c->bh->b); delete c->bh; c->bh = nullptr; }
+}
+
+int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
+                             float eps2, float G, float theta, float* ax, float* ay, float* az) {
+  if (n <= 0) return NB_OK;
+  if (n >= (1ll << 29)) return nb_fail(c, NB_ERR_ARG, "tree solver: n must be < 2^29");
+  if (n < 2 * 64 || !(theta > 0.f)) {
+    // tiny systems (or theta = 0: open everything) are exactly the direct sum
+    return nb_launch_accel_f32(c, x, y, z, n, x, y, z, m, n, eps2, G, ax, ay, az, 0);
+  }
+  if (!c->bh) c->bh = new nb_bh_state();
+  BHBuf& b = c->bh->b;
+  hipStream_t st = c->stream;
+  const int nn = (int)n;
+  if (b.cap < n) {
+    NB_HIP(c, hipStreamSynchronize(st));
+    bh_free(b);
+    const size_t N = (size_t)n, T = 2 * N;
+    NB_HIP(c, hipMalloc((void**)&b.bbox, (8 + 6 * 1024) * sizeof(float)));
+    NB_HIP(c, hipMalloc((void**)&b.keys, N * 8)); NB_HIP(c, hipMalloc((void**)&b.keys_sorted, N * 8));
+    NB_HIP(c, hipMalloc((void**)&b.idx, N * 4)); NB_HIP(c, hipMalloc((void**)&b.idx_sorted, N * 4));
+    NB_HIP(c, hipMalloc((void**)&b.sp, N * sizeof(float4)));
+    NB_HIP(c, hipMalloc((void**)&b.pre, 4 * N * sizeof(double)));
+    NB_HIP(c, hipMalloc((void**)&b.child, N * sizeof(int2)));
+    NB_HIP(c, hipMalloc((void**)&b.range, T * sizeof(int2)));
+    NB_HIP(c, hipMalloc((void**)&b.com, T * sizeof(float4)));
+    NB_HIP(c, hipMalloc((void**)&b.l2, T * sizeof(float)));
+    NB_HIP(c, hipMalloc((void**)&b.out, 3 * N * sizeof(float)));
+    size_t t1 = 0, t2 = 0;
+    NB_HIP(c, rocprim::radix_sort_pairs((void*)nullptr, t1, b.keys, b.keys_sorted, b.idx, b.idx_sorted, N, 0, 63, st));
+    NB_HIP(c, rocprim::inclusive_scan((void*)nullptr, t2, b.pre, b.pre, N, rocprim::plus<double>(), st));
+    b.tmp_bytes = (t1 > t2 ? t1 : t2) + 256;
+    NB_HIP(c, hipMalloc(&b.tmp, b.tmp_bytes));
+    b.cap = n;
+  }
+  float* part = b.bbox + 8;
+  const int gb = grid_for(n) > 1024 ? 1024 : grid_for(n);
+  bbox_partial_kernel<<<gb, 256, 0, st>>>(x, y, z, nn, part);
+  bbox_final_kernel<<<1, 64, 0, st>>>(part, gb, b.bbox);
+  morton_kernel<<<grid_for(n), 256, 0, st>>>(x, y, z, nn, b.bbox, b.keys, b.idx);
+  NB_HIP(c, hipGetLastError());
+  size_t tb = b.tmp_bytes;
+  NB_HIP(c, rocprim::radix_sort_pairs(b.tmp, tb, b.keys, b.keys_sorted, b.idx, b.idx_sorted, (size_t)n, 0, 63, st));
+  gather_kernel<<<grid_for(n), 256, 0, st>>>(x, y, z, m, b.idx_sorted, nn, b.sp, b.pre);
+  NB_HIP(c, hipGetLastError());
+  for (int k = 0; k < 4; ++k) {
+    tb = b.tmp_bytes;
+    NB_HIP(c, rocprim::inclusive_scan(b.tmp, tb, b.pre + (size_t)k * n, b.pre + (size_t)k * n, (size_t)n, rocprim::plus<double>(), st));
+  }
+  build_kernel<<<grid_for(n), 256, 0, st>>>(b.keys_sorted, nn, b.child, b.range, b.l2, b.bbox);
+  node_kernel<<<grid_for(2 * n), 256, 0, st>>>(b.pre, b.sp, nn, b.range, b.com, b.l2);
+  NB_HIP(c, hipGetLastError());
+  const int groups = (nn + 63) / 64;
+  const int blocks = (groups + 3) / 4;
+  if (eps2 > 0.f) walk_kernel<false><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out);
+  else walk_kernel<true><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out);
+  NB_HIP(c, hipGetLastError());
+  scatter_kernel<<<grid_for(n), 256, 0, st>>>(b.out, b.idx_sorted, nn, G, ax, ay, az);
+  NB_HIP(c, hipGetLastError());
+  return NB_OK;
+}

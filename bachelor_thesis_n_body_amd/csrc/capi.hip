@@ -92,6 +92,7 @@ int nb_destroy(nb_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
+  nb_bh_release(c);
   if (c->state) (void)hipFree(c->state);
   if (c->work) (void)hipFree(c->work);
   if (c->scal) (void)hipFree(c->scal);
@@ -108,6 +109,16 @@ int nb_set_stream(nb_ctx* c, void* hip_stream) {
   // the handle is used as given; NULL is HIP's default (null) stream, which is what torch's default stream is
   if (c->own_stream) { NB_HIP(c, hipStreamDestroy(c->stream)); c->own_stream = false; }
   c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return NB_OK;
+}
+
+int nb_set_solver(nb_ctx* c, int solver, double theta) {
+  if (!c) return NB_ERR_ARG;
+  if (solver != NB_SOLVER_DIRECT && solver != NB_SOLVER_TREE) return nb_fail(c, NB_ERR_ARG, "nb_set_solver: unknown solver");
+  if (solver == NB_SOLVER_TREE && c->dtype != NB_F32) return nb_fail(c, NB_ERR_ARG, "nb_set_solver: the tree solver is fp32 only");
+  if (solver == NB_SOLVER_TREE && !(theta >= 0.0 && theta < 2.0)) return nb_fail(c, NB_ERR_ARG, "nb_set_solver: theta must be in [0, 2)");
+  if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
+  c->solver = solver; c->theta = theta; c->acc_valid = false;
   return NB_OK;
 }
 
@@ -154,7 +165,13 @@ int nb_get_state(nb_ctx* c, void* x, void* y, void* z, void* vx, void* vy, void*
 // a(x) of the context's own particles into the state's ax/ay/az fields
 static int refresh_acc(nb_ctx* c, double eps, double G) {
   int rc;
-  if (c->dtype == NB_F32) {
+  if (c->solver == NB_SOLVER_TREE) {
+    if (c->dtype != NB_F32) return nb_fail(c, NB_ERR_ARG, "the tree solver is fp32 only");
+    float* s = reinterpret_cast<float*>(c->state);
+    const size_t n = (size_t)c->n;
+    rc = nb_launch_accel_tree_f32(c, s, s + n, s + 2 * n, s + 3 * n, c->n, (float)(eps * eps), (float)G, (float)c->theta,
+                                  s + 7 * n, s + 8 * n, s + 9 * n);
+  } else if (c->dtype == NB_F32) {
     float* s = reinterpret_cast<float*>(c->state);
     const size_t n = (size_t)c->n;
     rc = nb_launch_accel_f32(c, s, s + n, s + 2 * n, c->n, s, s + n, s + 2 * n, s + 3 * n, c->n,
@@ -215,7 +232,7 @@ int nb_step(nb_ctx* c, double dt, int64_t nsteps, double eps, double G) {
   // Launch-bound regime (small N, many steps): steps 1..n-1 are identical launch sequences
   // [kick_drift(h, h, dt); a(x)] with constant arguments, so capture one into a hipGraph and replay it.
   static const bool no_graph = getenv("NB_NO_GRAPH") != nullptr;
-  const bool use_graph = !no_graph && c->n <= 65536 && nsteps >= 4;
+  const bool use_graph = !no_graph && c->solver == NB_SOLVER_DIRECT && c->n <= 65536 && nsteps >= 4;
   for (int64_t k = 0; k < nsteps; ++k) {
     if (use_graph && k >= 1) {
       if (!c->step_graph || c->graph_dt != dt || c->graph_eps != eps || c->graph_G != G) {

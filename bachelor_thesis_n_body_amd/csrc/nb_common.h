@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <string>
 
+struct nb_bh_state;   // Barnes-Hut buffers (bh.hip)
+
 struct nb_ctx {
   int device = 0;
   int dtype = 0;              // NB_F32 / NB_F64
@@ -24,6 +26,10 @@ struct nb_ctx {
   // one KDK step [kick_drift(h,h,dt); a(x)] captured as a hipGraph and replayed for launch-bound (small-N) runs
   hipGraphExec_t step_graph = nullptr;
   double graph_dt = 0.0, graph_eps = -1.0, graph_G = 0.0;
+  // force solver used by nb_accel / nb_step: direct summation (default) or Barnes-Hut tree (fp32 only)
+  int solver = 0;
+  double theta = 0.5;
+  nb_bh_state* bh = nullptr;
   std::string err;
 };
 
@@ -45,6 +51,10 @@ int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float
 int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const double* zi, int64_t n_snk,
                         const double* xs, const double* ys, const double* zs, const double* ms, int64_t n_src,
                         double eps2, double G, double* ax, double* ay, double* az, int flags);
+// Barnes-Hut acceleration of n particles on themselves (fp32); falls back to the direct sum for n < 128 or theta <= 0
+int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
+                             float eps2, float G, float theta, float* ax, float* ay, float* az);
+void nb_bh_release(nb_ctx* c);
 int nb_launch_potential_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, const float* mi,
                             int64_t n_snk, int64_t snk_global0, const float* xs, const float* ys, const float* zs,
                             const float* ms, int64_t n_src, int64_t src_global0, float eps2, double* u_out,

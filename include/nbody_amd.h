@@ -35,6 +35,8 @@ extern "C" {
 typedef struct nb_ctx nb_ctx;
 
 enum { NB_F32 = 0, NB_F64 = 1 };
+/* force solvers selectable per context (nb_set_solver) */
+enum { NB_SOLVER_DIRECT = 0, NB_SOLVER_TREE = 1 };
 /* flags of nb_accel_dev */
 enum {
   NB_ACCUMULATE = 1,   /* add to the existing ax/ay/az instead of overwriting (source chunks arriving hop by hop) */
@@ -60,6 +62,10 @@ int nb_destroy(nb_ctx* ctx);
  * stream created by nb_create; the handle is used as given, NULL being HIP's default (null) stream */
 int nb_set_stream(nb_ctx* ctx, void* hip_stream);
 int nb_synchronize(nb_ctx* ctx);
+/* force solver used by nb_accel / nb_step of this context: NB_SOLVER_DIRECT (O(N^2), default) or NB_SOLVER_TREE =
+ * Barnes-Hut with opening angle theta (BASELINE.json configs[4]; fp32 contexts only; theta = 0 degenerates to the
+ * direct sum) */
+int nb_set_solver(nb_ctx* ctx, int solver, double theta);
 
 /* ---- host-pointer surface: the drop-in compute_forces()/step()/energy() (SURVEY §8a ⊕1-⊕3) ---- */
 int nb_set_state(nb_ctx* ctx, const void* x, const void* y, const void* z,

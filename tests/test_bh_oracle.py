@@ -1,0 +1,87 @@
+"""Pins the Barnes-Hut oracle (oracle/bh_oracle.c): structural invariants of the radix tree, convergence to the
+direct sum as theta -> 0, and the force-error level at the benchmark's theta = 0.5 (vs the direct-sum oracle)."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import bachelor_thesis_n_body_amd as nb
+from oracle import nbody_oracle as ora
+from conftest import rel_err
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+class BHOracle:
+    def __init__(self):
+        so = ROOT / "oracle" / "libbh_oracle.so"
+        if not so.exists():
+            subprocess.check_call(["make", "-C", str(ROOT / "oracle")], stdout=subprocess.DEVNULL)
+        self.lib = C.CDLL(str(so))
+
+    def accel(self, pos, mass, eps, G=1.0, theta=0.5):
+        p = np.ascontiguousarray(np.asarray(pos, np.float32).T)
+        m = np.ascontiguousarray(mass, np.float32)
+        n = p.shape[1]
+        a = np.zeros((3, n), np.float32)
+        st = np.zeros(3, np.int64)
+        v = lambda x: x.ctypes.data_as(C.c_void_p)
+        rc = self.lib.bho_accel_f32(C.c_int(n), v(p[0]), v(p[1]), v(p[2]), v(m), C.c_float(eps), C.c_float(G), C.c_float(theta),
+                                    v(a[0]), v(a[1]), v(a[2]), v(st))
+        assert rc == 0
+        return np.ascontiguousarray(a.T), st
+
+    def check_tree(self, pos, mass):
+        p = np.ascontiguousarray(np.asarray(pos, np.float32).T)
+        m = np.ascontiguousarray(mass, np.float32)
+        v = lambda x: x.ctypes.data_as(C.c_void_p)
+        return self.lib.bho_check_tree(C.c_int(p.shape[1]), v(p[0]), v(p[1]), v(p[2]), v(m))
+
+
+@pytest.fixture(scope="module")
+def bho():
+    return BHOracle()
+
+
+@pytest.mark.parametrize("n,seed", [(2, 0), (3, 1), (129, 2), (1000, 3), (20000, 4)])
+def test_tree_invariants(bho, n, seed):
+    s = nb.plummer_sphere(n, seed, np.float32)
+    assert bho.check_tree(s.pos, s.mass) == 0
+    # duplicate positions (identical Morton keys) and a degenerate axis must still give a valid tree
+    p = s.pos.copy()
+    p[: n // 2] = p[0]
+    p[:, 2] = 0.25
+    assert bho.check_tree(p, s.mass) == 0
+
+
+def test_bh_converges_to_direct_sum_and_error_level_at_theta_half(bho):
+    s = nb.plummer_sphere(8192, 5, np.float32)
+    ref = ora.compute_forces(s.pos.astype(np.float64), s.mass.astype(np.float64), 0.01)
+    errs = {}
+    for theta in (0.05, 0.25, 0.5, 0.8):
+        a, st = bho.accel(s.pos, s.mass, 0.01, theta=theta)
+        e = rel_err(a, ref)
+        errs[theta] = (np.median(e), np.percentile(e, 99), e.max())
+        assert st[0] + st[1] <= s.n * s.n          # never more work than the direct sum... for the pair count
+    assert errs[0.05][2] < 2e-4                     # essentially the direct sum
+    assert errs[0.25][0] < errs[0.5][0] < errs[0.8][0]
+    # monopole-only, cell-size MAC, group-wide acceptance: theta = 0.5 gives sub-percent forces
+    assert errs[0.5][0] < 3e-3 and errs[0.5][1] < 1.5e-2 and errs[0.5][2] < 5e-2
+    a, st = bho.accel(s.pos, s.mass, 0.01, theta=0.5)
+    assert st[0] + st[1] < 0.5 * s.n * s.n
+
+
+def test_bh_unequal_masses_and_zero_softening(bho):
+    rng = np.random.default_rng(0)
+    s = nb.plummer_sphere(3000, 6, np.float32)
+    mass = (s.mass * rng.uniform(0.2, 4.0, s.n)).astype(np.float32)
+    mass[::9] = 0
+    pos = s.pos.copy()
+    pos[7] = pos[1500]                                # coincident pair at eps = 0
+    a, _ = bho.accel(pos, mass, 0.0, G=2.0, theta=0.4)
+    assert np.all(np.isfinite(a))
+    ref = ora.compute_forces(pos.astype(np.float64), mass.astype(np.float64), 0.0, 2.0)
+    e = rel_err(a, ref)
+    assert np.median(e) < 3e-3 and np.percentile(e, 99) < 3e-2

@@ -1,0 +1,98 @@
+"""GPU Barnes-Hut (BASELINE.json configs[4]) vs its sequential oracle (oracle/bh_oracle.c, same tree / same walk) and
+vs direct summation.
+
+Tolerances: kernel and oracle take the same accept/open decisions (identical fp32 MAC arithmetic) except where a node's
+centre of mass differs in its last bit (parallel vs sequential fp64 prefix sums) and use different rsqrt roundings
+(v_rsq_f32 vs 1/sqrtf): >= 99 % of the particles agree to 2e-5, all to 2e-3 (a flipped decision changes one node's
+truncation error). Against the direct sum the error is the method's: median < 3e-3, 99th percentile < 1.5e-2 at theta = 0.5."""
+import numpy as np
+import pytest
+
+import bachelor_thesis_n_body_amd as nb
+from oracle import nbody_oracle as ora
+from conftest import rel_err
+from test_bh_oracle import BHOracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bho():
+    return BHOracle()
+
+
+@pytest.mark.parametrize("n,theta", [(128, 0.5), (1000, 0.5), (4097, 0.3), (30000, 0.5), (65536, 0.7)])
+def test_tree_matches_sequential_oracle(bho, n, theta):
+    s = nb.plummer_sphere(n, 40 + n % 7, np.float32)
+    a = nb.compute_forces(s.pos, s.mass, 0.01, method="tree", theta=theta)
+    want, _ = bho.accel(s.pos, s.mass, 0.01, theta=theta)
+    e = rel_err(a, want)
+    assert np.percentile(e, 99) < 2e-5, f"p99 {np.percentile(e, 99):.3e}"
+    assert e.max() < 2e-3, f"max {e.max():.3e}"
+
+
+def test_tree_error_vs_direct_sum_at_theta_half(coracle):
+    s = nb.plummer_sphere(65536, 1, np.float32)
+    a = nb.compute_forces(s.pos, s.mass, 0.01, method="tree", theta=0.5)
+    ref = coracle.accel(s.pos.astype(np.float64), s.mass.astype(np.float64), 0.01)
+    e = rel_err(a, ref)
+    assert np.median(e) < 3e-3 and np.percentile(e, 99) < 1.5e-2 and e.max() < 0.1
+    # Newton's third law only holds to the truncation error, but the net force must stay small
+    net = np.abs((s.mass[:, None].astype(np.float64) * a).sum(0)).max()
+    assert net < 1e-3 * (s.mass[:, None] * np.abs(a)).sum(0).max()
+
+
+def test_theta_zero_and_tiny_n_are_the_direct_sum():
+    s = nb.plummer_sphere(3000, 3, np.float32)
+    np.testing.assert_array_equal(nb.compute_forces(s.pos, s.mass, 0.01, method="tree", theta=0.0),
+                                  nb.compute_forces(s.pos, s.mass, 0.01))
+    t = nb.plummer_sphere(100, 3, np.float32)
+    np.testing.assert_array_equal(nb.compute_forces(t.pos, t.mass, 0.01, method="tree", theta=0.5),
+                                  nb.compute_forces(t.pos, t.mass, 0.01))
+
+
+def test_tree_unequal_masses_zero_softening_duplicates(bho):
+    rng = np.random.default_rng(0)
+    s = nb.plummer_sphere(5000, 6, np.float32)
+    mass = (s.mass * rng.uniform(0.2, 4.0, s.n)).astype(np.float32)
+    mass[::9] = 0
+    pos = s.pos.copy()
+    pos[7] = pos[1500]
+    pos[100:140] = pos[100]                           # 40 particles with one Morton key (> NLEAF)
+    a = nb.compute_forces(pos, mass, 0.0, G=2.0, method="tree", theta=0.4)
+    assert np.all(np.isfinite(a))
+    want, _ = bho.accel(pos, mass, 0.0, G=2.0, theta=0.4)
+    e = rel_err(a, want)
+    assert np.percentile(e, 99) < 5e-5 and e.max() < 5e-3
+
+
+def test_tree_solver_drives_the_integrator_and_is_fp32_only():
+    s = nb.plummer_sphere(4096, 9, np.float32)
+    with nb.Engine(s.n, np.float32) as e:
+        e.set_solver("tree", 0.4)
+        e.set_state(s)
+        k0, u0 = e.energy(0.02)
+        e.step(1 / 256, 20, 0.02)
+        k1, u1 = e.energy(0.02)
+        tree_state = e.get_state()
+        e.set_solver("direct")
+        e.set_state(s)
+        e.step(1 / 256, 20, 0.02)
+        direct_state = e.get_state()
+    assert abs((k1 + u1) - (k0 + u0)) < 2e-3 * abs(k0 + u0)
+    assert np.abs(tree_state.pos - direct_state.pos).max() < 5e-3
+    with nb.Engine(64, np.float64) as e:
+        with pytest.raises(RuntimeError, match="fp32 only"):
+            e.set_solver("tree", 0.5)
+
+
+def test_tree_large_n_sampled_against_direct_sum():
+    """N = 2^20: sampled sinks vs the oracle's direct sum over all sources."""
+    n = 1 << 20
+    s = nb.plummer_sphere(n, 0, np.float32)
+    a = nb.compute_forces(s.pos, s.mass, 0.01, method="tree", theta=0.5)
+    assert np.all(np.isfinite(a))
+    idx = np.random.default_rng(0).choice(n, 256, replace=False)
+    ref = ora.compute_forces(s.pos.astype(np.float64), s.mass.astype(np.float64), 0.01, sinks=s.pos[idx].astype(np.float64))
+    e = rel_err(a[idx], ref)
+    assert np.median(e) < 3e-3 and e.max() < 0.05
