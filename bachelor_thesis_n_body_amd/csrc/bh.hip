@@ -280,7 +280,7 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
   if (n >= (1ll << 29)) return nb_fail(c, NB_ERR_ARG, "tree solver: n must be < 2^29");
   if (n < 2 * 64 || !(theta > 0.f)) {
     // tiny systems (or theta = 0: open everything) are exactly the direct sum
-    return nb_launch_accel_f32(c, x, y, z, n, x, y, z, m, n, eps2, G, ax, ay, az, 0);
+    return nb_launch_accel_f32(c, x, y, z, n, x, y, z, m, n, eps2, G, ax, ay, az, c->uniform_mass ? NB_UNIFORM_MASS : 0);
   }
   if (!c->bh) c->bh = new nb_bh_state();
   BHBuf& b = c->bh->b;
