@@ -35,6 +35,23 @@ PEAK_FP32_VECTOR_TFLOPS = 157.3    # MI355X_MICROARCH.md "Peak FP32 (vector)"
 PEAK_FP64_VECTOR_TFLOPS = 78.6
 
 
+def measured_traffic():
+    """HBM bytes per accel launch from the committed rocprofv3 PMC passes of THIS command (tools/profile.sh ->
+    profiles/r01_bench_n1_uniform_rocprofv3_summary.txt: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE). bench.py
+    cannot run the profiler around itself, so the number is the profile's, or None if the file is absent."""
+    f = ROOT / "profiles" / "r01_bench_n1_uniform_rocprofv3_summary.txt"
+    try:
+        rd = wr = None
+        for line in f.read_text().splitlines():
+            if line.startswith("HBM read bytes/launch"):
+                rd = float(line.split("~")[1].split()[0])
+            if line.startswith("HBM write bytes/launch"):
+                wr = float(line.split("~")[1].split()[0])
+        return None if rd is None or wr is None else rd + wr
+    except OSError:
+        return None
+
+
 class KernelTimer:
     """HIP-event pairs around every accel launch, recorded on the stream the kernels run on (torch's current
     stream, which the engine binds with nb_set_stream)."""
@@ -182,7 +199,8 @@ def main():
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "flop_per_interaction": FLOP_PER_INTERACTION,
                          "interactions_per_launch": k_inter, "avg_launch_ms": k_ms, "launches_timed": k_count,
-                         "traffic": None},
+                         "traffic": measured_traffic() if (world == 1 and args.n == 1 << 20 and args.dtype == "f32") else None,
+                         "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC pass (profiles/); algorithmic bytes = 28*N"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(state, eps)
