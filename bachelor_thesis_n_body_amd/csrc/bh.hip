@@ -9,14 +9,20 @@
 //   4. node mass / centre of mass from fp64 prefix sums of m, m*x, m*y, m*z over the sorted order (no bottom-up
 //      pass, no inter-workgroup hand-off); node size l = edge of the Morton cell of the node's common prefix
 //                                                                                                  [node_kernel]
-//   5. traversal: one 64-lane wave per group of 64 consecutive sorted particles, one depth-first walk per wave with a
-//      wave-shared stack in LDS; a node is accepted when l^2 < theta^2 d^2 holds for EVERY lane of the wave
-//      (__all = wave ballot), d = distance lane particle -> node centre of mass; rejected nodes with <= NLEAF particles
-//      are summed directly, others push their two children. Node data and leaf particles are read with wave-uniform
-//      addresses. Accepted nodes interact as monopoles: a += G m_node d / (d^2 + eps^2)^{3/2}.    [walk_kernel]
+//   5. traversal, one 64-lane wave per group of 64 consecutive sorted particles. Two walks implement it:
+//      (list walk, default) [walk_list_kernel]: every pass pops up to 64 nodes from a wave-private stack, ONE NODE PER
+//      LANE, so 64 node records are fetched and tested at once instead of one dependent fetch per node. A node is
+//      accepted when l^2 < theta^2 d^2 with d the distance from the group's bounding box to the node's centre of mass;
+//      wave ballots compact the accepted nodes into an LDS monopole list, rejected nodes with <= NLEAF particles into
+//      a leaf list, and push the children of the rest. Then all lanes sweep the lists for their own particle: monopoles
+//      as LDS broadcasts, leaf particles staged 64 at a time into an LDS tile (the direct kernel's inner loop).
+//      (ballot walk, NB_BH_WALK=0) [walk_kernel]: one node at a time, accepted when l^2 < theta^2 d^2 holds for EVERY
+//      lane's own particle (__all); 15x slower (latency bound: one dependent node fetch per step), kept as a cross-check.
+//      Accepted nodes interact as monopoles: a += G m_node d / (d^2 + eps^2)^{3/2}.
 // Irregular, latency/issue bound (not a roofline kernel): measured numbers are in DESIGN.md.
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
+#include <cstdlib>
 #include <cstring>
 #include <string.h>
 #include <rocprim/rocprim.hpp>
@@ -37,6 +43,9 @@ struct BHBuf {
   float4* com = nullptr;                     // all nodes: (cx, cy, cz, mass)
   float* l2 = nullptr;                       // all nodes: cell edge squared
   float* out = nullptr;                      // [3][n] accelerations in sorted order
+  int4* rec = nullptr;                       // all nodes: (l2 bits, first, count, left child) for the list walk
+  int* gstack = nullptr;                     // wave-private stacks of the persistent list-walk waves
+  int* flags = nullptr;                      // [0] = stack overflow seen
   void* tmp = nullptr; size_t tmp_bytes = 0; // rocPRIM scratch
   int64_t cap = 0;
 };
@@ -166,7 +175,7 @@ build_kernel(const unsigned long long* __restrict__ k, int n, int2* __restrict__
 
 __global__ void __launch_bounds__(256)
 node_kernel(const double* __restrict__ pre, const float4* __restrict__ sp, int n, int2* __restrict__ range,
-            float4* __restrict__ com, float* __restrict__ l2) {
+            float4* __restrict__ com, float* __restrict__ l2, const int2* __restrict__ child, int4* __restrict__ rec) {
   const int total = 2 * n - 1;
   for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
     if (v >= n - 1) {                       // leaf
@@ -174,6 +183,7 @@ node_kernel(const double* __restrict__ pre, const float4* __restrict__ sp, int n
       range[v] = make_int2(j, 1);
       com[v] = sp[j];
       l2[v] = 0.0f;
+      rec[v] = make_int4(0, j, 1, -1);
       continue;
     }
     const int2 r = range[v];
@@ -188,6 +198,7 @@ node_kernel(const double* __restrict__ pre, const float4* __restrict__ sp, int n
       o = make_float4(p.x, p.y, p.z, 0.0f);
     }
     com[v] = o;
+    rec[v] = make_int4(__float_as_int(l2[v]), r.x, r.y, child[v].x);
   }
 }
 
@@ -246,6 +257,124 @@ walk_kernel(const float4* __restrict__ sp, int n, const int2* __restrict__ child
   if (live) { out[i] = ax; out[(size_t)n + i] = ay; out[2 * (size_t)n + i] = az; }
 }
 
+constexpr int LSTACK = 12288;      // entries per wave-private stack (<= 128 nodes left behind per tree level, depth <= 96)
+
+// The list walk (see the header). Stack entries live in global memory (L2-resident, wave-private); entries written by
+// one lane are read by another lane of the same wave in a later pass, so every store is drained (s_waitcnt vmcnt(0))
+// before the next pass loads, and the loads bypass the vector L1.
+template <bool GUARD>
+__global__ void __launch_bounds__(256)
+walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict__ com, const int4* __restrict__ rec,
+                 float theta2, float eps2, float* __restrict__ out, int* __restrict__ gstack, int ngroups,
+                 int* __restrict__ flags) {
+  __shared__ float4 mono_all[4][64];
+  __shared__ float4 tile_all[4][64];
+  __shared__ int lf_first_all[4][64];
+  __shared__ int lf_pref_all[4][65];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  volatile float4* mono = mono_all[wave];
+  volatile float4* tile = tile_all[wave];
+  volatile int* lf_first = lf_first_all[wave];
+  volatile int* lf_pref = lf_pref_all[wave];
+  const int wid = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+  int* stack = gstack + (size_t)wid * LSTACK;
+
+  for (int group = wid; group < ngroups; group += nwaves) {
+    const int i = group * 64 + lane;
+    const bool live = i < n;
+    const float4 me = sp[live ? i : n - 1];
+    // bounding box of the group's particles (butterfly over the wave)
+    float lo[3] = {me.x, me.y, me.z}, hi[3] = {me.x, me.y, me.z};
+#pragma unroll
+    for (int w = 1; w < 64; w <<= 1)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        lo[c] = fminf(lo[c], __shfl_xor(lo[c], w));
+        hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], w));
+      }
+    float gc[3], gh[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gc[c] = 0.5f * (lo[c] + hi[c]); gh[c] = 0.5f * (hi[c] - lo[c]); }
+
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    int top = 1;
+    if (lane == 0) stack[0] = 0;                 // root
+    while (top > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stack stores of the previous pass have reached L2
+      const int k = top < 64 ? top : 64;
+      top -= k;
+      int v = -1;
+      if (lane < k) v = __hip_atomic_load(&stack[top + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+      int4 r = make_int4(0, 0, 0, -1);
+      if (v >= 0) { c = com[v]; r = rec[v]; }
+      // distance from the group's box to the node's centre of mass
+      const float ex = fmaxf(fabsf(c.x - gc[0]) - gh[0], 0.f);
+      const float ey = fmaxf(fabsf(c.y - gc[1]) - gh[1], 0.f);
+      const float ez = fmaxf(fabsf(c.z - gc[2]) - gh[2], 0.f);
+      const float d2 = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
+      const bool is_leaf = v >= n - 1;
+      const bool accept = v >= 0 && !is_leaf && __int_as_float(r.x) < theta2 * d2;
+      const bool leafy = v >= 0 && !accept && (is_leaf || r.z <= NLEAF);
+      const bool open = v >= 0 && !accept && !leafy;
+      const unsigned long long m_acc = __ballot(accept), m_leaf = __ballot(leafy), m_open = __ballot(open);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const int n_acc = __popcll(m_acc), n_leaf = __popcll(m_leaf), n_open = __popcll(m_open);
+      if (accept) { const int p = __popcll(m_acc & below); mono[p].x = c.x; mono[p].y = c.y; mono[p].z = c.z; mono[p].w = c.w; }
+      // inclusive prefix of the leaf counts, in lane order
+      int cnt = leafy ? r.z : 0, pre = cnt;
+#pragma unroll
+      for (int w = 1; w < 64; w <<= 1) { const int t = __shfl_up(pre, w); if (lane >= w) pre += t; }
+      // compact: entry e (e-th leafy lane) -> first particle and exclusive prefix
+      if (leafy) { const int p = __popcll(m_leaf & below); lf_first[p] = r.y; lf_pref[p] = pre - cnt; }
+      const int total_leaf = __shfl(pre, 63);
+      if (lane == 0) lf_pref[n_leaf] = total_leaf;
+      if (open) {
+        const int p = __popcll(m_open & below);
+        const int left = r.w;
+        const int gamma = left >= n - 1 ? left - (n - 1) : left;
+        const int right = (r.y + r.z - 1 == gamma + 1) ? (n - 1 + gamma + 1) : (gamma + 1);
+        if (top + 2 * n_open <= LSTACK) { stack[top + 2 * p] = right; stack[top + 2 * p + 1] = left; }
+      }
+      if (n_open > 0) {
+        if (top + 2 * n_open <= LSTACK) top += 2 * n_open;
+        else if (lane == 0) flags[0] = 1;                       // overflow: results invalid, reported by the host
+      }
+      // ---- monopoles of this pass
+      for (int e = 0; e < n_acc; ++e) {
+        const float qx = mono[e].x, qy = mono[e].y, qz = mono[e].z, qm = mono[e].w;   // LDS broadcast
+        const float dx = qx - me.x, dy = qy - me.y, dz = qz - me.z;
+        const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) + eps2;
+        float rinv = __builtin_amdgcn_rsqf(r2);
+        if (GUARD) rinv = r2 > 0.f ? rinv : 0.f;
+        const float f = qm * rinv * rinv * rinv;
+        ax = fmaf(f, dx, ax); ay = fmaf(f, dy, ay); az = fmaf(f, dz, az);
+      }
+      // ---- particles of the leaf ranges, 64 at a time through an LDS tile
+      for (int base = 0; base < total_leaf; base += 64) {
+        const int t = base + lane;
+        if (t < total_leaf) {
+          int a = 0, b = n_leaf;                                  // last entry with lf_pref[e] <= t
+          while (b - a > 1) { const int mid = (a + b) >> 1; if (lf_pref[mid] <= t) a = mid; else b = mid; }
+          const float4 q = sp[lf_first[a] + (t - lf_pref[a])];
+          tile[lane].x = q.x; tile[lane].y = q.y; tile[lane].z = q.z; tile[lane].w = q.w;
+        }
+        const int m = total_leaf - base < 64 ? total_leaf - base : 64;
+        for (int e = 0; e < m; ++e) {
+          const float qx = tile[e].x, qy = tile[e].y, qz = tile[e].z, qm = tile[e].w;
+          const float dx = qx - me.x, dy = qy - me.y, dz = qz - me.z;
+          const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) + eps2;
+          float rinv = __builtin_amdgcn_rsqf(r2);
+          if (GUARD) rinv = r2 > 0.f ? rinv : 0.f;
+          const float f = qm * rinv * rinv * rinv;
+          ax = fmaf(f, dx, ax); ay = fmaf(f, dy, ay); az = fmaf(f, dz, az);
+        }
+      }
+    }
+    if (live) { out[i] = ax; out[(size_t)n + i] = ay; out[2 * (size_t)n + i] = az; }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 scatter_kernel(const float* __restrict__ sorted_out, const int* __restrict__ idx, int n, float G,
                float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az) {
@@ -265,9 +394,19 @@ inline int grid_for(int64_t n) {
 struct nb_bh_state { BHBuf b; };
 
 static void bh_free(BHBuf& b) {
-  void* p[] = {b.bbox, b.keys, b.keys_sorted, b.idx, b.idx_sorted, b.sp, b.pre, b.child, b.range, b.com, b.l2, b.out, b.tmp};
+  void* p[] = {b.bbox, b.keys, b.keys_sorted, b.idx, b.idx_sorted, b.sp, b.pre, b.child, b.range, b.com, b.l2, b.out, b.tmp,
+               b.rec, b.gstack, b.flags};
   for (void* q : p) if (q) (void)hipFree(q);
   b = BHBuf();
+}
+
+// after a stream sync: did a list-walk stack overflow (results invalid)?
+int nb_bh_check(nb_ctx* c) {
+  if (!c->bh || !c->bh->b.flags) return NB_OK;
+  int f = 0;
+  NB_HIP(c, hipMemcpy(&f, c->bh->b.flags, sizeof(int), hipMemcpyDeviceToHost));
+  if (f) { (void)hipMemset(c->bh->b.flags, 0, sizeof(int)); return nb_fail(c, NB_ERR_STATE, "tree walk: stack overflow (results invalid); set NB_BH_WALK=0"); }
+  return NB_OK;
 }
 
 void nb_bh_release(nb_ctx* c) {
@@ -300,6 +439,13 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
     NB_HIP(c, hipMalloc((void**)&b.com, T * sizeof(float4)));
     NB_HIP(c, hipMalloc((void**)&b.l2, T * sizeof(float)));
     NB_HIP(c, hipMalloc((void**)&b.out, 3 * N * sizeof(float)));
+    NB_HIP(c, hipMalloc((void**)&b.rec, T * sizeof(int4)));
+    {
+      const int groups = (int)((N + 63) / 64), blocks = (groups + 3) / 4 < 2048 ? (groups + 3) / 4 : 2048;
+      NB_HIP(c, hipMalloc((void**)&b.gstack, (size_t)blocks * 4 * LSTACK * sizeof(int)));
+    }
+    NB_HIP(c, hipMalloc((void**)&b.flags, 4 * sizeof(int)));
+    NB_HIP(c, hipMemsetAsync(b.flags, 0, 4 * sizeof(int), st));
     size_t t1 = 0, t2 = 0;
     NB_HIP(c, rocprim::radix_sort_pairs((void*)nullptr, t1, b.keys, b.keys_sorted, b.idx, b.idx_sorted, N, 0, 63, st));
     NB_HIP(c, rocprim::inclusive_scan((void*)nullptr, t2, b.pre, b.pre, N, rocprim::plus<double>(), st));
@@ -322,12 +468,19 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
     NB_HIP(c, rocprim::inclusive_scan(b.tmp, tb, b.pre + (size_t)k * n, b.pre + (size_t)k * n, (size_t)n, rocprim::plus<double>(), st));
   }
   build_kernel<<<grid_for(n), 256, 0, st>>>(b.keys_sorted, nn, b.child, b.range, b.l2, b.bbox);
-  node_kernel<<<grid_for(2 * n), 256, 0, st>>>(b.pre, b.sp, nn, b.range, b.com, b.l2);
+  node_kernel<<<grid_for(2 * n), 256, 0, st>>>(b.pre, b.sp, nn, b.range, b.com, b.l2, b.child, b.rec);
   NB_HIP(c, hipGetLastError());
   const int groups = (nn + 63) / 64;
   const int blocks = (groups + 3) / 4;
-  if (eps2 > 0.f) walk_kernel<false><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out);
-  else walk_kernel<true><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out);
+  static const int walk_mode = getenv("NB_BH_WALK") ? atoi(getenv("NB_BH_WALK")) : 1;
+  if (walk_mode == 0) {
+    if (eps2 > 0.f) walk_kernel<false><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out);
+    else walk_kernel<true><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out);
+  } else {
+    const int pblocks = blocks < 2048 ? blocks : 2048;      // persistent waves: <= 8 blocks per CU, groups strided
+    if (eps2 > 0.f) walk_list_kernel<false><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.out, b.gstack, groups, b.flags);
+    else walk_list_kernel<true><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.out, b.gstack, groups, b.flags);
+  }
   NB_HIP(c, hipGetLastError());
   scatter_kernel<<<grid_for(n), 256, 0, st>>>(b.out, b.idx_sorted, nn, G, ax, ay, az);
   NB_HIP(c, hipGetLastError());

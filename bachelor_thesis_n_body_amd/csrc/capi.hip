@@ -200,7 +200,7 @@ int nb_accel(nb_ctx* c, double eps, double G, void* ax, void* ay, void* az) {
   for (int f = 0; f < 3; ++f)
     if (dst[f]) NB_HIP(c, hipMemcpyAsync(dst[f], base + (size_t)(7 + f) * b, b, hipMemcpyDeviceToHost, c->stream));
   NB_HIP(c, hipStreamSynchronize(c->stream));
-  return NB_OK;
+  return nb_bh_check(c);
 }
 
 int nb_get_acc(nb_ctx* c, void* ax, void* ay, void* az) {
@@ -260,7 +260,7 @@ int nb_step(nb_ctx* c, double dt, int64_t nsteps, double eps, double G) {
   }
   rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, h); if (rc) return rc;
   NB_HIP(c, hipStreamSynchronize(c->stream));
-  return NB_OK;
+  return nb_bh_check(c);
 }
 
 int nb_energy(nb_ctx* c, double eps, double G, double* kinetic, double* potential) {

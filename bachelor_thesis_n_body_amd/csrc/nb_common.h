@@ -55,6 +55,7 @@ int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const dou
 int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
                              float eps2, float G, float theta, float* ax, float* ay, float* az);
 void nb_bh_release(nb_ctx* c);
+int nb_bh_check(nb_ctx* c);   // call after a stream sync
 int nb_launch_potential_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, const float* mi,
                             int64_t n_snk, int64_t snk_global0, const float* xs, const float* ys, const float* zs,
                             const float* ms, int64_t n_src, int64_t src_global0, float eps2, double* u_out,

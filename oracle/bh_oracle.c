@@ -200,6 +200,89 @@ int bho_accel_f32(int n, const float* x, const float* y, const float* z, const f
   return 0;
 }
 
+/* The LIST walk of bh.hip (walk_list_kernel), executed sequentially with the same pass structure: every pass pops up to
+ * 64 nodes from the top of the stack ("lane" L takes stack[top - k + L]); a node is accepted when l^2 < theta^2 d^2 with d
+ * the distance from the group's bounding box to the node's centre of mass; accepted nodes form the pass's monopole list
+ * (lane order), rejected nodes with <= NLEAF particles its leaf list, the others push (right, left) in lane order. Each
+ * particle of the group then adds the monopoles in list order and the leaf particles in list order. */
+int bho_accel_list_f32(int n, const float* x, const float* y, const float* z, const float* m, float eps, float G,
+                       float theta, float* ax, float* ay, float* az, int64_t* stats) {
+  if (n < 128 || !(theta > 0.f)) return -1;
+  tree_t t;
+  tree_build(&t, n, x, y, z, m);
+  const float eps2 = eps * eps, theta2 = theta * theta;
+  int64_t st[4] = {0, 0, 0, 0};
+  const int cap = 1 << 20;
+  int* stack = (int*)malloc(sizeof(int) * cap);
+  for (int g0 = 0; g0 < n; g0 += 64) {
+    const int g1 = g0 + 64 < n ? g0 + 64 : n;
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int i = g0; i < g1; ++i) {
+      const float v[3] = {t.sx[i], t.sy[i], t.sz[i]};
+      for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], v[c]); hi[c] = fmaxf(hi[c], v[c]); }
+    }
+    float gc[3], gh[3];
+    for (int c = 0; c < 3; ++c) { gc[c] = 0.5f * (lo[c] + hi[c]); gh[c] = 0.5f * (hi[c] - lo[c]); }
+    float fx[64], fy[64], fz[64];
+    for (int q = 0; q < 64; ++q) fx[q] = fy[q] = fz[q] = 0.f;
+    int top = 0;
+    stack[top++] = 0;
+    while (top > 0) {
+      const int k = top < 64 ? top : 64;
+      top -= k;
+      int popped[64], mono[64], leaf[64], nm = 0, nl = 0, no = 0, opened[64];
+      for (int L = 0; L < k; ++L) popped[L] = stack[top + L];
+      if (top + k > st[3]) st[3] = top + k;
+      for (int L = 0; L < k; ++L) {
+        const int v = popped[L];
+        ++st[2];
+        const int is_leaf = v >= n - 1;
+        const float ex = fmaxf(fabsf(t.cx[v] - gc[0]) - gh[0], 0.f);
+        const float ey = fmaxf(fabsf(t.cy[v] - gc[1]) - gh[1], 0.f);
+        const float ez = fmaxf(fabsf(t.cz[v] - gc[2]) - gh[2], 0.f);
+        const float d2 = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
+        if (!is_leaf && t.l2[v] < theta2 * d2) mono[nm++] = v;
+        else if (is_leaf || t.count[v] <= NLEAF) leaf[nl++] = v;
+        else opened[no++] = v;
+      }
+      for (int p = 0; p < no; ++p) { stack[top + 2 * p] = t.right[opened[p]]; stack[top + 2 * p + 1] = t.left[opened[p]]; }
+      top += 2 * no;
+      for (int i = g0; i < g1; ++i) {
+        float a0 = fx[i - g0], a1 = fy[i - g0], a2 = fz[i - g0];
+        for (int e = 0; e < nm; ++e) {
+          const int v = mono[e];
+          const float dx = t.cx[v] - t.sx[i], dy = t.cy[v] - t.sy[i], dz = t.cz[v] - t.sz[i];
+          const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) + eps2;
+          const float rinv = r2 > 0.f ? 1.0f / sqrtf(r2) : 0.f;
+          const float f = t.cm[v] * rinv * rinv * rinv;
+          a0 = fmaf(f, dx, a0); a1 = fmaf(f, dy, a1); a2 = fmaf(f, dz, a2);
+        }
+        for (int e = 0; e < nl; ++e) {
+          const int v = leaf[e];
+          for (int j = t.first[v]; j < t.first[v] + t.count[v]; ++j) {
+            const float dx = t.sx[j] - t.sx[i], dy = t.sy[j] - t.sy[i], dz = t.sz[j] - t.sz[i];
+            const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) + eps2;
+            const float rinv = r2 > 0.f ? 1.0f / sqrtf(r2) : 0.f;
+            const float f = t.sm[j] * rinv * rinv * rinv;
+            a0 = fmaf(f, dx, a0); a1 = fmaf(f, dy, a1); a2 = fmaf(f, dz, a2);
+          }
+        }
+        fx[i - g0] = a0; fy[i - g0] = a1; fz[i - g0] = a2;
+      }
+      st[0] += (int64_t)nm * (g1 - g0);
+      for (int e = 0; e < nl; ++e) st[1] += (int64_t)t.count[leaf[e]] * (g1 - g0);
+    }
+    for (int i = g0; i < g1; ++i) {
+      const int j = t.kv[i].idx;
+      ax[j] = G * fx[i - g0]; ay[j] = G * fy[i - g0]; az[j] = G * fz[i - g0];
+    }
+  }
+  if (stats) { stats[0] = st[0]; stats[1] = st[1]; stats[2] = st[2]; stats[3] = st[3]; }
+  free(stack);
+  tree_free(&t);
+  return 0;
+}
+
 /* Tree invariants for tests: returns 0 if every internal node's children partition its range, the root covers
  * [0, n), node masses equal the sum of their leaves (to 1e-6), else a positive error code. */
 int bho_check_tree(int n, const float* x, const float* y, const float* z, const float* m) {

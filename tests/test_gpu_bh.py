@@ -23,9 +23,10 @@ def bho():
 
 @pytest.mark.parametrize("n,theta", [(128, 0.5), (1000, 0.5), (4097, 0.3), (30000, 0.5), (65536, 0.7)])
 def test_tree_matches_sequential_oracle(bho, n, theta):
+    """Default (list) walk vs the oracle's sequential execution of the same pass structure."""
     s = nb.plummer_sphere(n, 40 + n % 7, np.float32)
     a = nb.compute_forces(s.pos, s.mass, 0.01, method="tree", theta=theta)
-    want, _ = bho.accel(s.pos, s.mass, 0.01, theta=theta)
+    want, _ = bho.accel(s.pos, s.mass, 0.01, theta=theta, walk="list")
     e = rel_err(a, want)
     assert np.percentile(e, 99) < 2e-5, f"p99 {np.percentile(e, 99):.3e}"
     assert e.max() < 2e-3, f"max {e.max():.3e}"
@@ -61,7 +62,7 @@ def test_tree_unequal_masses_zero_softening_duplicates(bho):
     pos[100:140] = pos[100]                           # 40 particles with one Morton key (> NLEAF)
     a = nb.compute_forces(pos, mass, 0.0, G=2.0, method="tree", theta=0.4)
     assert np.all(np.isfinite(a))
-    want, _ = bho.accel(pos, mass, 0.0, G=2.0, theta=0.4)
+    want, _ = bho.accel(pos, mass, 0.0, G=2.0, theta=0.4, walk="list")
     e = rel_err(a, want)
     assert np.percentile(e, 99) < 5e-5 and e.max() < 5e-3
 
@@ -96,3 +97,25 @@ def test_tree_large_n_sampled_against_direct_sum():
     ref = ora.compute_forces(s.pos.astype(np.float64), s.mass.astype(np.float64), 0.01, sinks=s.pos[idx].astype(np.float64))
     e = rel_err(a[idx], ref)
     assert np.median(e) < 3e-3 and e.max() < 0.05
+
+
+def test_ballot_walk_variant_matches_its_oracle(bho):
+    """NB_BH_WALK=0 selects the one-node-at-a-time all-lanes-ballot walk (the env var is read once per process, so
+    this runs in a child process)."""
+    import subprocess, sys, textwrap, os
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import bachelor_thesis_n_body_amd as nb
+        from test_bh_oracle import BHOracle
+        from conftest import rel_err
+        s = nb.plummer_sphere(20000, 3, np.float32)
+        a = nb.compute_forces(s.pos, s.mass, 0.01, method="tree", theta=0.5)
+        want, _ = BHOracle().accel(s.pos, s.mass, 0.01, theta=0.5, walk="ballot")
+        e = rel_err(a, want)
+        assert np.percentile(e, 99) < 2e-5 and e.max() < 2e-3, (np.percentile(e, 99), e.max())
+        print("ok")
+    """) % (str(__import__("pathlib").Path(__file__).resolve().parent.parent), str(__import__("pathlib").Path(__file__).resolve().parent))
+    env = dict(os.environ, NB_BH_WALK="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
