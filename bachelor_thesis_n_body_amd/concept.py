@@ -1,0 +1,129 @@
+"""`concept`-style command line for the engine (first slice).
+
+The thesis drives its solver as a subprocess:
+    [<run_dir>/bin/concept, "-p", <param file>, "-n", "1", "--local"]          SnapVsPK/Ucertain.py:89-97,
+                                                                               TheFeedingPipeline/NeuNetværk_test.py:155-171
+reads nothing from it but the exit status, and later opens `<output_dirs['snapshot']>/snapshot_a=1.00.hdf5`
+(`FraP_kTilDelta.py:129-146`). This module accepts that command line and that parameter-file subset
+(`params.py`) and leaves the same artefacts behind, so a farm script can point `concept` at
+`python -m bachelor_thesis_n_body_amd.concept`.
+
+SCOPE — what it is NOT: CONCEPT integrates comoving coordinates in an expanding background with periodic (Ewald)
+forces and LPT velocities; this engine integrates the ISOLATED NEWTONIAN problem. Only
+`select_forces = {'matter': {'gravity': 'pp'}}` is accepted; the scale factors in `output_times` are used as file labels,
+the run length is `--steps` fixed KDK steps of `--dt` Gyr. Initial conditions: a CONCEPT snapshot (`--ic`, or
+`initial_conditions = '<path>'`), or a Zel'dovich-displaced lattice of N = n^3 particles at rest from a tabulated P(k)
+(`--pk-table`, two columns k [1/Mpc], P [Mpc^3]) seeded by `random_seeds`.
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+
+from . import params as _params
+
+
+def _write_powerspec(path: Path, k, pk, counts, a: float, ngrid: int) -> None:
+    """Text table in the column order of CONCEPT's powerspec files (k, modes, P; PPPMP3M/PP/powerspec/powerspec_a=1.00:10-26)."""
+    with open(path, "w", encoding="utf-8") as fh:
+        fh.write(f"# Power spectrum from bachelor_thesis_n_body_amd at a = {a:g}\n#\n# grid size {ngrid}\n")
+        fh.write("#  k [Mpc⁻¹]   modes     P [Mpc³]\n")
+        for ki, ci, pi in zip(k, counts, pk):
+            fh.write(f"{ki:.7e} {int(ci):6d}  {pi:.7e}\n")
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="concept", description=__doc__.split("\n\n")[0])
+    ap.add_argument("-p", "--param", required=True)
+    ap.add_argument("-n", "--nprocs", default="1", help="accepted for compatibility (one process per GPU)")
+    ap.add_argument("--local", action="store_true", help="accepted for compatibility")
+    ap.add_argument("-c", "--command-line-param", action="append", default=[], help="extra `name = value` lines")
+    ap.add_argument("--ic", help="CONCEPT-layout snapshot to start from")
+    ap.add_argument("--pk-table", help="two-column text file k [1/Mpc], P(k) [Mpc^3] for generated initial conditions")
+    ap.add_argument("--dt", type=float, default=0.01, help="KDK step in Gyr")
+    ap.add_argument("--steps", type=int, default=0)
+    ap.add_argument("--eps", type=float, default=None, help="Plummer softening in Mpc (default 0.03 mean separations)")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f64")
+    ap.add_argument("--solver", choices=["direct", "tree"], default="direct")
+    ap.add_argument("--theta", type=float, default=0.5)
+    args = ap.parse_args(argv)
+
+    try:
+        p = _params.parse(args.param)
+        for line in args.command_line_param:
+            exec(line, {**_params.UNITS}, p)
+        s = _params.settings(p)
+    except _params.ParamError as e:
+        print(f"concept: {e}", file=sys.stderr)
+        return 2
+    if s["gravity"] != "pp":
+        print(f"concept: select_forces gravity = {s['gravity']!r}: this engine implements direct summation ('pp') only",
+              file=sys.stderr)
+        return 3
+    if not s["snapshot_dir"]:
+        print("concept: output_dirs['snapshot'] missing", file=sys.stderr)
+        return 2
+
+    from . import Engine, State, field, grf, snapshot   # needs the HIP library from here on
+
+    L = s["boxsize"]
+    ic_file = args.ic or s["ic_file"]
+    if ic_file:
+        pos = snapshot.read_positions(ic_file)
+        mom = snapshot.read_momenta(ic_file)
+        attrs = snapshot.read_attrs(ic_file, "components/matter")
+        mass = float(attrs.get("mass", 1.0))
+        vel = mom / mass
+        n = pos.shape[0]
+    else:
+        n_side = round(s["N"] ** (1.0 / 3.0))
+        if n_side ** 3 != s["N"]:
+            print(f"concept: initial_conditions['N'] = {s['N']} is not a cube", file=sys.stderr)
+            return 2
+        if not args.pk_table:
+            print("concept: generated initial conditions need --pk-table (CLASS is not available to this engine)", file=sys.stderr)
+            return 2
+        tab = np.loadtxt(args.pk_table)
+        P = grf.tabulated_pk_grid(tab[:, 0], tab[:, 1], n_side, L)
+        seeds = s["random_seeds"]
+        c_1 = np.random.default_rng(int(seeds.get("primordial amplitudes", 0))).normal(0, 1 / np.sqrt(2), (n_side,) * 3)
+        c_2 = np.random.default_rng(int(seeds.get("primordial phases", 1))).normal(0, 1 / np.sqrt(2), (n_side,) * 3)
+        pos = grf.zeldovich_particles(P, c_1, c_2, L, "skip_self")
+        vel = np.zeros_like(pos)
+        n = pos.shape[0]
+        rho_m = (float(p.get("Ωb", 0.049)) + float(p.get("Ωcdm", 0.264))) * 3 * float(p["H0"]) ** 2 / (8 * np.pi * _params.G_NEWTON) \
+            if p.get("H0") else 1.0
+        mass = rho_m * L ** 3 / n
+    eps = args.eps if args.eps is not None else 0.03 * L / round(n ** (1.0 / 3.0))
+    dtype = np.float32 if args.dtype == "f32" else np.float64
+    state = State(pos.astype(dtype), vel.astype(dtype), np.full(n, mass, dtype))
+    if args.steps > 0:
+        with Engine(n, dtype) as e:
+            if args.solver == "tree":
+                e.set_solver("tree", args.theta)
+            e.set_state(state)
+            e.step(args.dt, args.steps, eps, _params.G_NEWTON)
+            state = e.get_state()
+    out = Path(s["snapshot_dir"])
+    out.mkdir(parents=True, exist_ok=True)
+    labels = s["snapshot_times"] or [1.0]
+    for a in labels:
+        snapshot.write_snapshot(str(out / f"snapshot_a={a:.2f}.hdf5"), np.mod(state.pos.astype(np.float64), L),
+                                state.vel.astype(np.float64) * mass, L, mass=mass,
+                                extra_attrs={"a": float(a), "H0": float(p["H0"]) if p.get("H0") else 0.0})
+    if s["powerspec_dir"] or s["powerspec_times"]:
+        pdir = Path(s["powerspec_dir"] or out.parent / "powerspec")
+        pdir.mkdir(parents=True, exist_ok=True)
+        ngrid = max(2, round(n ** (1.0 / 3.0)))
+        k, pk, cnt = field.power_spectrum(np.mod(state.pos.astype(np.float64), L), L, ngrid, deconvolve=True)
+        for a in (s["powerspec_times"] or labels):
+            _write_powerspec(pdir / f"powerspec_a={a:.2f}", k, pk, cnt, a, ngrid)
+    print(f"concept: wrote {len(labels)} snapshot(s) to {out}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

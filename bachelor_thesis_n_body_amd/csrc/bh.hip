@@ -12,7 +12,8 @@
 //   5. traversal, one 64-lane wave per group of 64 consecutive sorted particles. Two walks implement it:
 //      (list walk, default) [walk_list_kernel]: every pass pops up to 64 nodes from a wave-private stack, ONE NODE PER
 //      LANE, so 64 node records are fetched and tested at once instead of one dependent fetch per node. A node is
-//      accepted when l^2 < theta^2 d^2 with d the distance from the group's bounding box to the node's centre of mass;
+//      accepted when l^2 < theta^2 d^2 for every particle of the group (d^2 = the minimum over the group's 64 particles of
+//      the squared distance to the node's centre of mass, each lane scanning the group's positions in LDS);
 //      wave ballots compact the accepted nodes into an LDS monopole list, rejected nodes with <= NLEAF particles into
 //      a leaf list, and push the children of the rest. Then all lanes sweep the lists for their own particle: monopoles
 //      as LDS broadcasts, leaf particles staged 64 at a time into an LDS tile (the direct kernel's inner loop).
@@ -269,13 +270,20 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
                  int* __restrict__ flags) {
   __shared__ float4 mono_all[4][64];
   __shared__ float4 tile_all[4][64];
+  __shared__ float4 gpos_all[4][64];
   __shared__ int lf_first_all[4][64];
   __shared__ int lf_pref_all[4][65];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  volatile float4* mono = mono_all[wave];
-  volatile float4* tile = tile_all[wave];
-  volatile int* lf_first = lf_first_all[wave];
-  volatile int* lf_pref = lf_pref_all[wave];
+  // wave-private LDS lists: written by some lanes, then read by all lanes of the SAME wave. LDS operations of one wave
+  // execute in order, so only the compiler has to be told (wavefront-scope fences around a wave barrier) — volatile
+  // accesses would serialise the sweeps below into dependent dword reads (measured 15x slower).
+  float4* mono = mono_all[wave];
+  float4* tile = tile_all[wave];
+  float4* gpos = gpos_all[wave];
+  int* lf_first = lf_first_all[wave];
+  int* lf_pref = lf_pref_all[wave];
+#define NB_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
   const int wid = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
   int* stack = gstack + (size_t)wid * LSTACK;
 
@@ -283,19 +291,12 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
     const int i = group * 64 + lane;
     const bool live = i < n;
     const float4 me = sp[live ? i : n - 1];
-    // bounding box of the group's particles (butterfly over the wave)
-    float lo[3] = {me.x, me.y, me.z}, hi[3] = {me.x, me.y, me.z};
-#pragma unroll
-    for (int w = 1; w < 64; w <<= 1)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        lo[c] = fminf(lo[c], __shfl_xor(lo[c], w));
-        hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], w));
-      }
-    float gc[3], gh[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { gc[c] = 0.5f * (lo[c] + hi[c]); gh[c] = 0.5f * (hi[c] - lo[c]); }
-
+    // the group's particle positions, for the per-node minimum-distance test (padding lanes repeat a live particle).
+    // A bounding-box test would be cheaper but is pathological here: 64 CONSECUTIVE Morton-ordered particles can
+    // straddle a jump of the curve, and a box spanning the dense core forces it to be opened down to its leaves
+    // (measured: a few such groups ran 100x longer than the rest).
+    gpos[lane] = me;
+    NB_WAVE_SYNC();
     float ax = 0.f, ay = 0.f, az = 0.f;
     int top = 1;
     if (lane == 0) stack[0] = 0;                 // root
@@ -308,11 +309,14 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
       float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
       int4 r = make_int4(0, 0, 0, -1);
       if (v >= 0) { c = com[v]; r = rec[v]; }
-      // distance from the group's box to the node's centre of mass
-      const float ex = fmaxf(fabsf(c.x - gc[0]) - gh[0], 0.f);
-      const float ey = fmaxf(fabsf(c.y - gc[1]) - gh[1], 0.f);
-      const float ez = fmaxf(fabsf(c.z - gc[2]) - gh[2], 0.f);
-      const float d2 = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
+      // smallest squared distance from any particle of the group to this lane's node
+      float d2 = 3.4e38f;
+#pragma unroll 8
+      for (int e = 0; e < 64; ++e) {
+        const float4 g = gpos[e];                                  // LDS broadcast
+        const float ex = c.x - g.x, ey = c.y - g.y, ez = c.z - g.z;
+        d2 = fminf(d2, fmaf(ex, ex, fmaf(ey, ey, ez * ez)));
+      }
       const bool is_leaf = v >= n - 1;
       const bool accept = v >= 0 && !is_leaf && __int_as_float(r.x) < theta2 * d2;
       const bool leafy = v >= 0 && !accept && (is_leaf || r.z <= NLEAF);
@@ -320,7 +324,7 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
       const unsigned long long m_acc = __ballot(accept), m_leaf = __ballot(leafy), m_open = __ballot(open);
       const unsigned long long below = (1ull << lane) - 1ull;
       const int n_acc = __popcll(m_acc), n_leaf = __popcll(m_leaf), n_open = __popcll(m_open);
-      if (accept) { const int p = __popcll(m_acc & below); mono[p].x = c.x; mono[p].y = c.y; mono[p].z = c.z; mono[p].w = c.w; }
+      if (accept) mono[__popcll(m_acc & below)] = c;
       // inclusive prefix of the leaf counts, in lane order
       int cnt = leafy ? r.z : 0, pre = cnt;
 #pragma unroll
@@ -340,10 +344,13 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
         if (top + 2 * n_open <= LSTACK) top += 2 * n_open;
         else if (lane == 0) flags[0] = 1;                       // overflow: results invalid, reported by the host
       }
+      NB_WAVE_SYNC();
       // ---- monopoles of this pass
+#pragma unroll 4
       for (int e = 0; e < n_acc; ++e) {
-        const float qx = mono[e].x, qy = mono[e].y, qz = mono[e].z, qm = mono[e].w;   // LDS broadcast
-        const float dx = qx - me.x, dy = qy - me.y, dz = qz - me.z;
+        const float4 q = mono[e];                                                    // LDS broadcast (ds_read_b128)
+        const float qm = q.w;
+        const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
         const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) + eps2;
         float rinv = __builtin_amdgcn_rsqf(r2);
         if (GUARD) rinv = r2 > 0.f ? rinv : 0.f;
@@ -356,23 +363,29 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
         if (t < total_leaf) {
           int a = 0, b = n_leaf;                                  // last entry with lf_pref[e] <= t
           while (b - a > 1) { const int mid = (a + b) >> 1; if (lf_pref[mid] <= t) a = mid; else b = mid; }
-          const float4 q = sp[lf_first[a] + (t - lf_pref[a])];
-          tile[lane].x = q.x; tile[lane].y = q.y; tile[lane].z = q.z; tile[lane].w = q.w;
+          tile[lane] = sp[lf_first[a] + (t - lf_pref[a])];
         }
+        NB_WAVE_SYNC();
         const int m = total_leaf - base < 64 ? total_leaf - base : 64;
+#pragma unroll 4
         for (int e = 0; e < m; ++e) {
-          const float qx = tile[e].x, qy = tile[e].y, qz = tile[e].z, qm = tile[e].w;
-          const float dx = qx - me.x, dy = qy - me.y, dz = qz - me.z;
+          const float4 q = tile[e];
+          const float qm = q.w;
+          const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
           const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) + eps2;
           float rinv = __builtin_amdgcn_rsqf(r2);
           if (GUARD) rinv = r2 > 0.f ? rinv : 0.f;
           const float f = qm * rinv * rinv * rinv;
           ax = fmaf(f, dx, ax); ay = fmaf(f, dy, ay); az = fmaf(f, dz, az);
         }
+        NB_WAVE_SYNC();                        // the tile is rewritten by the next chunk
       }
+      NB_WAVE_SYNC();                          // the lists are rewritten by the next pass
     }
     if (live) { out[i] = ax; out[(size_t)n + i] = ay; out[2 * (size_t)n + i] = az; }
+    NB_WAVE_SYNC();                            // gpos is rewritten for the next group
   }
+#undef NB_WAVE_SYNC
 }
 
 __global__ void __launch_bounds__(256)
@@ -441,7 +454,7 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
     NB_HIP(c, hipMalloc((void**)&b.out, 3 * N * sizeof(float)));
     NB_HIP(c, hipMalloc((void**)&b.rec, T * sizeof(int4)));
     {
-      const int groups = (int)((N + 63) / 64), blocks = (groups + 3) / 4 < 2048 ? (groups + 3) / 4 : 2048;
+      const int groups = (int)((N + 63) / 64), blocks = (groups + 3) / 4 < 1024 ? (groups + 3) / 4 : 1024;
       NB_HIP(c, hipMalloc((void**)&b.gstack, (size_t)blocks * 4 * LSTACK * sizeof(int)));
     }
     NB_HIP(c, hipMalloc((void**)&b.flags, 4 * sizeof(int)));
@@ -477,7 +490,7 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
     if (eps2 > 0.f) walk_kernel<false><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out);
     else walk_kernel<true><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out);
   } else {
-    const int pblocks = blocks < 2048 ? blocks : 2048;      // persistent waves: <= 8 blocks per CU, groups strided
+    const int pblocks = blocks < 1024 ? blocks : 1024;      // persistent waves: 4 blocks per CU (all resident), groups strided
     if (eps2 > 0.f) walk_list_kernel<false><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.out, b.gstack, groups, b.flags);
     else walk_list_kernel<true><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.out, b.gstack, groups, b.flags);
   }

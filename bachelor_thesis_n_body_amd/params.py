@@ -1,0 +1,122 @@
+"""Reader for the subset of CONCEPT `.param` files the thesis uses.
+
+The reference's parameter files are executable Python with unit symbols, `_user` variables and a `path` object
+(`Different_Sizes/Giant.param:1-85`, `TheFeedingPipeline/NN.param:1-95`, `SnapVsPK/Uncertain.param`), templated by
+line-rewriting in `SnapVsPK/Ucertain.py:22-67` and `TheFeedingPipeline/NeuNetværk_test.py:79-120` (which prepend
+`path.output_dir = ...`, `path.job_dir = ...` and a `random_seeds = {...}` block). This module evaluates such a file
+in a namespace that provides those symbols and returns the handful of keys the engine understands:
+
+    initial_conditions['N'], boxsize, output_dirs['snapshot'], output_times['snapshot'],
+    select_forces[species]['gravity'], random_seeds, primordial_spectrum, a_begin, H0, Ωb, Ωcdm
+
+Unit system: Mpc = Gyr = 1, mass unit 1e10 m_sun — the units CONCEPT records in its snapshots
+(`unit length`, `unit time`, `unit mass` root attributes).  Forward references (NN.param uses `primordial_spectrum`
+in `_tag` 90 lines before defining it) are resolved by evaluating the statements repeatedly until no new one succeeds.
+"""
+from __future__ import annotations
+
+import ast
+import math
+from pathlib import Path
+from types import SimpleNamespace
+from typing import Any, Dict
+
+# units: Mpc, Gyr, 1e10 m_sun
+_KM = 1.0 / 3.0856775814913673e19          # km in Mpc
+_S = 1.0 / 3.15576e16                      # s in Gyr (Julian year)
+UNITS = {
+    "Mpc": 1.0, "kpc": 1e-3, "pc": 1e-6, "Gpc": 1e3, "km": _KM, "m": _KM * 1e-3,
+    "Gyr": 1.0, "Myr": 1e-3, "kyr": 1e-6, "yr": 1e-9, "s": _S, "minutes": 60 * _S, "hr": 3600 * _S, "day": 86400 * _S,
+    "m_sun": 1e-10, "km_s": _KM / _S,
+    "pi": math.pi, "π": math.pi, "sqrt": math.sqrt, "cbrt": lambda x: x ** (1.0 / 3.0), "inf": math.inf,
+    "exp": math.exp, "log": math.log, "sin": math.sin, "cos": math.cos,
+}
+G_NEWTON = 4.300917270e-9 * (1e10) * (_KM / _S) ** 2   # G in Mpc^3 / (1e10 m_sun) / Gyr^2  (4.3009e-9 Mpc km^2 s^-2 / m_sun)
+
+
+class ParamError(ValueError):
+    pass
+
+
+class _Namespace(dict):
+    """Globals of the parameter file: `h` is derived lazily from H0 (Giant.param:78-80 writes `0.02237 /h**2`)."""
+
+    def __missing__(self, key):
+        if key == "h":
+            if "H0" not in self:
+                raise NameError("h")
+            return self["H0"] / (100 * UNITS["km"] / (UNITS["s"] * UNITS["Mpc"]))
+        raise KeyError(key)
+
+
+def parse(path, overrides: Dict[str, Any] | None = None) -> Dict[str, Any]:
+    """Evaluate a `.param` file and return its user-visible variables (a plain dict, plus 'path')."""
+    text = Path(path).read_text(encoding="utf-8")
+    try:
+        tree = ast.parse(text, filename=str(path))
+    except SyntaxError as e:
+        raise ParamError(f"{path}: {e}") from e
+    ns = _Namespace(UNITS)
+    ns["__builtins__"] = {"range": range, "len": len, "int": int, "float": float, "str": str, "min": min, "max": max,
+                          "abs": abs, "round": round, "sum": sum, "NameError": NameError, "True": True, "False": False,
+                          "None": None, "dict": dict, "list": list, "tuple": tuple, "set": set, "print": print}
+    base = Path(path).resolve().parent
+    ns["path"] = SimpleNamespace(output_dir=str(base / "output"), ic_dir=str(base / "ic"), job_dir=str(base / "job"),
+                                 param_dir=str(base), concept_dir=str(base))
+    for k, v in (overrides or {}).items():
+        ns[k] = v
+    pending = list(tree.body)
+    errors: Dict[int, Exception] = {}
+    while pending:
+        still = []
+        for node in pending:
+            code = compile(ast.Module(body=[node], type_ignores=[]), str(path), "exec")
+            try:
+                exec(code, ns)
+            except (NameError, KeyError) as e:     # forward reference: try again after the rest
+                errors[id(node)] = e
+                still.append(node)
+            except Exception as e:
+                raise ParamError(f"{path}:{getattr(node, 'lineno', '?')}: {type(e).__name__}: {e}") from e
+        if len(still) == len(pending):
+            node = still[0]
+            raise ParamError(f"{path}:{getattr(node, 'lineno', '?')}: unresolved name: {errors[id(node)]}")
+        pending = still
+    out = {k: v for k, v in ns.items() if k not in UNITS and k != "__builtins__"}
+    return out
+
+
+def settings(p: Dict[str, Any]) -> Dict[str, Any]:
+    """The keys the engine acts on, validated (SURVEY.md §8f-4 list)."""
+    ic = p.get("initial_conditions")
+    if isinstance(ic, dict):
+        n = int(ic.get("N", 0))
+        species = ic.get("species", "matter")
+    elif isinstance(ic, str):
+        n, species = 0, "matter"
+    else:
+        raise ParamError("initial_conditions missing")
+    if "boxsize" not in p:
+        raise ParamError("boxsize missing")
+    forces = p.get("select_forces", {})
+    gravity = None
+    for comp, d in forces.items():
+        if isinstance(d, dict) and "gravity" in d:
+            gravity = d["gravity"]
+    out_dirs = p.get("output_dirs", {})
+    times = p.get("output_times", {})
+    snap_times = times.get("snapshot", times.get("a", {}).get("snapshot", [])) if isinstance(times, dict) else []
+    if not isinstance(snap_times, (list, tuple)):
+        snap_times = [snap_times]
+    return {
+        "N": n, "species": species, "ic_file": ic if isinstance(ic, str) else None,
+        "boxsize": float(p["boxsize"]),
+        "snapshot_dir": out_dirs.get("snapshot"), "powerspec_dir": out_dirs.get("powerspec"),
+        "snapshot_times": [float(t) for t in snap_times],
+        "powerspec_times": [float(t) for t in (times.get("powerspec", []) if isinstance(times, dict) else [])],
+        "gravity": gravity,
+        "random_seeds": dict(p.get("random_seeds", {})),
+        "primordial_spectrum": dict(p.get("primordial_spectrum", {})),
+        "a_begin": float(p.get("a_begin", 1.0)),
+        "H0": p.get("H0"), "Ωb": p.get("Ωb"), "Ωcdm": p.get("Ωcdm"),
+    }

@@ -201,8 +201,8 @@ int bho_accel_f32(int n, const float* x, const float* y, const float* z, const f
 }
 
 /* The LIST walk of bh.hip (walk_list_kernel), executed sequentially with the same pass structure: every pass pops up to
- * 64 nodes from the top of the stack ("lane" L takes stack[top - k + L]); a node is accepted when l^2 < theta^2 d^2 with d
- * the distance from the group's bounding box to the node's centre of mass; accepted nodes form the pass's monopole list
+ * 64 nodes from the top of the stack ("lane" L takes stack[top - k + L]); a node is accepted when l^2 < theta^2 d^2 with d^2
+ * the minimum over the group's particles of the squared distance to the node's centre of mass (= for EVERY particle); accepted nodes form the pass's monopole list
  * (lane order), rejected nodes with <= NLEAF particles its leaf list, the others push (right, left) in lane order. Each
  * particle of the group then adds the monopoles in list order and the leaf particles in list order. */
 int bho_accel_list_f32(int n, const float* x, const float* y, const float* z, const float* m, float eps, float G,
@@ -216,13 +216,6 @@ int bho_accel_list_f32(int n, const float* x, const float* y, const float* z, co
   int* stack = (int*)malloc(sizeof(int) * cap);
   for (int g0 = 0; g0 < n; g0 += 64) {
     const int g1 = g0 + 64 < n ? g0 + 64 : n;
-    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
-    for (int i = g0; i < g1; ++i) {
-      const float v[3] = {t.sx[i], t.sy[i], t.sz[i]};
-      for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], v[c]); hi[c] = fmaxf(hi[c], v[c]); }
-    }
-    float gc[3], gh[3];
-    for (int c = 0; c < 3; ++c) { gc[c] = 0.5f * (lo[c] + hi[c]); gh[c] = 0.5f * (hi[c] - lo[c]); }
     float fx[64], fy[64], fz[64];
     for (int q = 0; q < 64; ++q) fx[q] = fy[q] = fz[q] = 0.f;
     int top = 0;
@@ -237,10 +230,11 @@ int bho_accel_list_f32(int n, const float* x, const float* y, const float* z, co
         const int v = popped[L];
         ++st[2];
         const int is_leaf = v >= n - 1;
-        const float ex = fmaxf(fabsf(t.cx[v] - gc[0]) - gh[0], 0.f);
-        const float ey = fmaxf(fabsf(t.cy[v] - gc[1]) - gh[1], 0.f);
-        const float ez = fmaxf(fabsf(t.cz[v] - gc[2]) - gh[2], 0.f);
-        const float d2 = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
+        float d2 = 3.4e38f;
+        for (int i = g0; i < g1; ++i) {
+          const float ex = t.cx[v] - t.sx[i], ey = t.cy[v] - t.sy[i], ez = t.cz[v] - t.sz[i];
+          d2 = fminf(d2, fmaf(ex, ex, fmaf(ey, ey, ez * ez)));
+        }
         if (!is_leaf && t.l2[v] < theta2 * d2) mono[nm++] = v;
         else if (is_leaf || t.count[v] <= NLEAF) leaf[nl++] = v;
         else opened[no++] = v;
