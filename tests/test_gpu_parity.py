@@ -305,3 +305,20 @@ def test_engine_detects_uniform_and_nonuniform_masses():
     a_gen = nb.compute_forces(s.pos, m2, 0.01)
     assert rel_err(a_uni, ora.compute_forces(s.pos.astype(np.float64), s.mass.astype(np.float64), 0.01)).max() < TOL[np.float32]
     assert rel_err(a_gen, ora.compute_forces(s.pos.astype(np.float64), m2.astype(np.float64), 0.01)).max() < TOL[np.float32]
+
+
+# ------------------------------------------------------------------ energy conservation at scale (configs[3] in small)
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 2e-5), (np.float32, 5e-5)])
+def test_energy_conservation_large_n(dtype, tol):
+    """N = 2^18 Plummer sphere, 20 KDK steps of dt = 1/256: the relative energy error stays at the integrator's level
+    (the fp64 run is the scaled-down version of BASELINE configs[3]; fp32 adds only round-off thanks to the fp64 flush)."""
+    n = 1 << 18
+    s = nb.plummer_sphere(n, 2, dtype)
+    with nb.Engine(n, dtype) as e:
+        e.set_state(s)
+        k0, u0 = e.energy(0.01)
+        e.step(1 / 256, 20, 0.01)
+        k1, u1 = e.energy(0.01)
+    e0, e1 = k0 + u0, k1 + u1
+    assert abs(2 * k0 / abs(u0) - 1) < 0.02 and abs(e0 + 0.25) < 0.01       # virial, Hénon units
+    assert abs(e1 - e0) / abs(e0) < tol, f"dE/E = {(e1 - e0) / abs(e0):.3e}"
