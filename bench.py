@@ -200,7 +200,7 @@ def main():
                          "flop_per_interaction": FLOP_PER_INTERACTION,
                          "interactions_per_launch": k_inter, "avg_launch_ms": k_ms, "launches_timed": k_count,
                          "traffic": measured_traffic() if (world == 1 and args.n == 1 << 20 and args.dtype == "f32") else None,
-                         "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC pass (profiles/); algorithmic bytes = 28*N"},
+                         "traffic_source": "rocprofv3 PMC pass of this command committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE); algorithmic bytes = 28*N"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(state, eps)

@@ -48,7 +48,7 @@ def _worker(rank, world, port, n, mode, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,mode", [(2, 96, "ring"), (2, 97, "allgather"), (3, 50, "ring")])
+@pytest.mark.parametrize("world,n,mode", [(2, 96, "ring"), (2, 97, "allgather"), (3, 50, "ring"), (4, 131, "ring")])
 def test_sharded_engine_matches_single_process_oracle(tmp_path, world, n, mode):
     from oracle import nbody_oracle as ora
     import bachelor_thesis_n_body_amd as nb
