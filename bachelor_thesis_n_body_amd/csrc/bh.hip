@@ -267,7 +267,7 @@ template <bool GUARD>
 __global__ void __launch_bounds__(256)
 walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict__ com, const int4* __restrict__ rec,
                  float theta2, float eps2, float* __restrict__ out, int* __restrict__ gstack, int ngroups,
-                 int* __restrict__ flags) {
+                 int* __restrict__ flags, int nleaf) {
   __shared__ float4 mono_all[4][64];
   __shared__ float4 tile_all[4][64];
   __shared__ float4 gpos_all[4][64];
@@ -287,7 +287,14 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
   const int wid = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
   int* stack = gstack + (size_t)wid * LSTACK;
 
-  for (int group = wid; group < ngroups; group += nwaves) {
+  // groups are handed out dynamically (flags[1] is a work counter zeroed by the host): their cost varies by >10x
+  // between the halo and the core, static striding left a tail of late waves
+  (void)nwaves;
+  for (;;) {
+    int group = 0;
+    if (lane == 0) group = atomicAdd(&flags[1], 1);
+    group = __builtin_amdgcn_readfirstlane(group);
+    if (group >= ngroups) break;
     const int i = group * 64 + lane;
     const bool live = i < n;
     const float4 me = sp[live ? i : n - 1];
@@ -319,7 +326,7 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
       }
       const bool is_leaf = v >= n - 1;
       const bool accept = v >= 0 && !is_leaf && __int_as_float(r.x) < theta2 * d2;
-      const bool leafy = v >= 0 && !accept && (is_leaf || r.z <= NLEAF);
+      const bool leafy = v >= 0 && !accept && (is_leaf || r.z <= nleaf);
       const bool open = v >= 0 && !accept && !leafy;
       const unsigned long long m_acc = __ballot(accept), m_leaf = __ballot(leafy), m_open = __ballot(open);
       const unsigned long long below = (1ull << lane) - 1ull;
@@ -454,7 +461,7 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
     NB_HIP(c, hipMalloc((void**)&b.out, 3 * N * sizeof(float)));
     NB_HIP(c, hipMalloc((void**)&b.rec, T * sizeof(int4)));
     {
-      const int groups = (int)((N + 63) / 64), blocks = (groups + 3) / 4 < 1024 ? (groups + 3) / 4 : 1024;
+      const int groups = (int)((N + 63) / 64), blocks = (groups + 3) / 4 < 2048 ? (groups + 3) / 4 : 2048;
       NB_HIP(c, hipMalloc((void**)&b.gstack, (size_t)blocks * 4 * LSTACK * sizeof(int)));
     }
     NB_HIP(c, hipMalloc((void**)&b.flags, 4 * sizeof(int)));
@@ -490,9 +497,12 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
     if (eps2 > 0.f) walk_kernel<false><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out);
     else walk_kernel<true><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out);
   } else {
-    const int pblocks = blocks < 1024 ? blocks : 1024;      // persistent waves: 4 blocks per CU (all resident), groups strided
-    if (eps2 > 0.f) walk_list_kernel<false><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.out, b.gstack, groups, b.flags);
-    else walk_list_kernel<true><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.out, b.gstack, groups, b.flags);
+    static const int maxb = getenv("NB_BH_BLOCKS") ? atoi(getenv("NB_BH_BLOCKS")) : 1792;   // 7 blocks per CU (VGPR-limited residency); <= 2048 (stack allocation)
+    const int pblocks = blocks < maxb ? blocks : maxb;      // persistent waves; groups are handed out dynamically
+    static const int nleaf = getenv("NB_BH_NLEAF") ? atoi(getenv("NB_BH_NLEAF")) : NLEAF;
+    NB_HIP(c, hipMemsetAsync(b.flags + 1, 0, sizeof(int), st));                 // dynamic group counter
+    if (eps2 > 0.f) walk_list_kernel<false><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.out, b.gstack, groups, b.flags, nleaf);
+    else walk_list_kernel<true><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.out, b.gstack, groups, b.flags, nleaf);
   }
   NB_HIP(c, hipGetLastError());
   scatter_kernel<<<grid_for(n), 256, 0, st>>>(b.out, b.idx_sorted, nn, G, ax, ay, az);
