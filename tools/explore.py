@@ -43,17 +43,17 @@ if __name__ == "__main__":
         for n in (1000, 4096, 30000):
             parity(n, np.float32); parity(n, np.float64)
     if what in ("all", "f32"):
-        for ks, u in ((2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2)):
-            os.environ["NB_F32_KS"] = str(ks); os.environ["NB_F32_U"] = str(u)
+        for ks in (2, 4, 8):
+            os.environ["NB_F32_KS"] = str(ks)
             for n in (65536, 1048576):
-                rate(n, np.float32, label=f"KS={ks} U={u}")
-        os.environ.pop("NB_F32_KS"); os.environ.pop("NB_F32_U")
+                rate(n, np.float32, label=f"KS={ks}")
+        os.environ.pop("NB_F32_KS")
     if what == "tune":
         for n in (16384, 65536, 262144):
-            for ks, u in ((2, 2), (4, 2), (8, 2)):
+            for ks in (2, 4, 8):
                 for split in (0, 4, 8, 16, 32, 64):
-                    os.environ["NB_F32_KS"] = str(ks); os.environ["NB_F32_U"] = str(u); os.environ["NB_F32_SPLIT"] = str(split)
-                    rate(n, np.float32, reps=5, label=f"KS={ks} U={u} SPLIT={split}")
+                    os.environ["NB_F32_KS"] = str(ks); os.environ["NB_F32_SPLIT"] = str(split)
+                    rate(n, np.float32, reps=5, label=f"KS={ks} SPLIT={split}")
     if what in ("all", "f64"):
         for mode in (0, 1):
             for ks in (1, 2, 4):
