@@ -28,6 +28,8 @@ SIGNATURES = {
     "nb_set_stream": (_int, [_vp, _vp]),
     "nb_synchronize": (_int, [_vp]),
     "nb_set_solver": (_int, [_vp, _int, _dbl]),
+    "nb_set_periodic": (_int, [_vp, _dbl, _dbl, _int]),
+    "nb_kdk_step": (_int, [_vp, _dbl, _dbl, _dbl, _dbl, _dbl]),
     "nb_set_state": (_int, [_vp] + [_vp] * 7),
     "nb_get_state": (_int, [_vp] + [_vp] * 7),
     "nb_accel": (_int, [_vp, _dbl, _dbl, _vp, _vp, _vp]),

@@ -72,6 +72,14 @@ class Engine:
         code = {"direct": _lib.NB_SOLVER_DIRECT, "tree": _lib.NB_SOLVER_TREE}[method]
         _lib.check(self._ctx, self._lib.nb_set_solver(self._ctx, code, float(theta)), "nb_set_solver")
 
+    def set_periodic(self, boxsize: float, alpha_L: float = 6.2, kmax: int = 7) -> None:
+        """Cubic periodic box (Ewald summation, uniform background subtracted); boxsize <= 0 switches it off. fp64 only."""
+        _lib.check(self._ctx, self._lib.nb_set_periodic(self._ctx, float(boxsize), float(alpha_L), int(kmax)), "nb_set_periodic")
+
+    def kdk_step(self, kick1: float, drift: float, kick2: float, eps: float, G: float = 1.0) -> None:
+        """v += a*kick1; x += v*drift; a = a(x); v += a*kick2 (comoving leapfrog with kick = int dt/a, drift = int dt/a^2)."""
+        _lib.check(self._ctx, self._lib.nb_kdk_step(self._ctx, kick1, drift, kick2, eps, G), "nb_kdk_step")
+
     def synchronize(self) -> None:
         _lib.check(self._ctx, self._lib.nb_synchronize(self._ctx), "nb_synchronize")
 

@@ -1,0 +1,127 @@
+"""Cosmological (comoving, periodic) direct-summation runs — the physics of the reference's one `pp` run
+(SURVEY.md §0 item 2, §8f-4): 64^3 particles in a 500 Mpc periodic box from a = 0.02 to 1
+(`PPPMP3M/pppmp3mplotter.py:11-22`), parameters as in `Different_Sizes/Giant.param:75-85`.
+
+Host side (NumPy): flat LCDM background, growth factor, kick/drift integrals, Zel'dovich initial conditions from a
+tabulated linear P(k) (CLASS is not available: the spectrum is an input — e.g. the `P linear` column of the reference's own
+`powerspec_a=1.00`). Device side: periodic Ewald forces and the generalised KDK step of the C-ABI
+(`nb_set_periodic`, `nb_kdk_step`), GRF synthesis (`grf.py`), P(k) estimator (`field.py`).
+
+Equations (comoving positions x, v := a^2 dx/dt = canonical momentum per unit mass, as in CONCEPT / GADGET):
+    dx/dt = v / a^2,   dv/dt = g(x) / a,   g = G sum_j m_j d_ij / |d_ij|^3  (periodic, mean density subtracted)
+    KDK over [a0, a1]:  v += g K(a0, am);  x += v D(a0, a1);  g = g(x);  v += g K(am, a1)
+    K(a, b) = int_a^b da' / (a'^2 H(a')),   D(a, b) = int_a^b da' / (a'^3 H(a')),   am = sqrt(a0 a1)
+Units: Mpc, Gyr, 1e10 M_sun (`params.py`).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import numpy as np
+
+from . import params as _params
+
+
+@dataclass
+class Cosmology:
+    H0: float            # 1/Gyr
+    Om: float            # matter (baryons + CDM)
+    Or: float = 0.0      # radiation (photons + massless neutrinos)
+
+    @classmethod
+    def from_h_omegas(cls, h: float, omega_b: float, omega_cdm: float, radiation: bool = True) -> "Cosmology":
+        """h, omega_b = Omega_b h^2, omega_cdm as in Giant.param:75-80 (`H0 = 67.36*km/(s*Mpc)`, `Ωb = 0.02237/h**2`)."""
+        H0 = 100.0 * h * _params.UNITS["km"] / _params.UNITS["s"]
+        Orr = (2.473e-5 * (1.0 + 0.2271 * 3.046)) / h ** 2 if radiation else 0.0
+        return cls(H0, (omega_b + omega_cdm) / h ** 2, Orr)
+
+    def E(self, a):
+        a = np.asarray(a, np.float64)
+        return np.sqrt(self.Or / a ** 4 + self.Om / a ** 3 + (1.0 - self.Om - self.Or))
+
+    def H(self, a):
+        return self.H0 * self.E(a)
+
+    def kick_factor(self, a0: float, a1: float, n: int = 65) -> float:
+        a = np.linspace(a0, a1, n)
+        return float(np.trapezoid(1.0 / (a ** 2 * self.H(a)), a))
+
+    def drift_factor(self, a0: float, a1: float, n: int = 65) -> float:
+        a = np.linspace(a0, a1, n)
+        return float(np.trapezoid(1.0 / (a ** 3 * self.H(a)), a))
+
+    def _D_un(self, a: float, n: int = 4000) -> float:
+        x = np.linspace(1e-8, a, n)
+        return float(self.E(a) * np.trapezoid(1.0 / (x * self.E(x)) ** 3, x))
+
+    def growth(self, a: float):
+        """(D(a) with D(1) = 1, f = dlnD/dlna) — the integral solution for flat LCDM."""
+        d1 = self._D_un(1.0)
+        h = 1e-4 * a
+        f = (np.log(self._D_un(a + h)) - np.log(self._D_un(a - h))) / (np.log(a + h) - np.log(a - h))
+        return self._D_un(a) / d1, float(f)
+
+    def particle_mass(self, boxsize: float, n: int, G: float = _params.G_NEWTON) -> float:
+        rho_m = self.Om * 3.0 * self.H0 ** 2 / (8.0 * np.pi * G)
+        return rho_m * boxsize ** 3 / n
+
+
+def zeldovich_ics(pk_table, n_side: int, boxsize: float, cosmo: Cosmology, a_begin: float, seed_amp: int = 0,
+                  seed_phase: int = 1):
+    """Lattice + growing-mode displacement at a_begin from the LINEAR spectrum at a = 1 (two columns k, P):
+    returns comoving positions (N,3) in [0, L) and v = a^2 dx/dt (N,3)."""
+    from . import grf
+    tab = np.asarray(pk_table, np.float64)
+    D, f = cosmo.growth(a_begin)
+    # grf's amplitude carries the thesis' `fac` = sqrt(2 pi / V) N^3; the standard convention is sqrt(P / V) N^3
+    P = grf.tabulated_pk_grid(tab[:, 0], tab[:, 1], n_side, boxsize) * D * D / (2.0 * np.pi)
+    c_1 = np.random.default_rng(int(seed_amp)).normal(0, 1 / np.sqrt(2), (n_side,) * 3)
+    c_2 = np.random.default_rng(int(seed_phase)).normal(0, 1 / np.sqrt(2), (n_side,) * 3)
+    with grf.GRFPlan(n_side, boxsize) as plan:
+        plan.set_noise(c_1, c_2, "skip_self")
+        plan.set_spectrum(P)
+        psi = np.stack([plan.field(c + 1).reshape(-1) for c in range(3)], axis=1)
+    g = np.linspace(0, boxsize, n_side, endpoint=False)
+    q = np.array(np.meshgrid(g, g, g, indexing="ij")).reshape(3, -1).T
+    pos = np.mod(q + psi, boxsize)
+    vel = (a_begin ** 2 * float(cosmo.H(a_begin)) * f) * psi          # a^2 dx/dt with x = q + D(a) psi_1
+    return pos, vel
+
+
+def run_pp(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: float, a_end: float = 1.0, nsteps: int = 400,
+           eps: Optional[float] = None, alpha_L: float = 6.2, kmax: int = 7,
+           callback: Optional[Callable[[float, "object"], None]] = None, device: int = 0):
+    """Comoving periodic `pp` run on the GPU with `nsteps` steps uniform in ln a. Returns (pos, vel) at a_end."""
+    from .api import Engine
+    from .state import State
+    n = pos.shape[0]
+    if eps is None:
+        eps = 0.03 * boxsize / round(n ** (1.0 / 3.0))
+    edges = np.exp(np.linspace(np.log(a_begin), np.log(a_end), nsteps + 1))
+    with Engine(n, np.float64, device) as e:
+        e.set_periodic(boxsize, alpha_L, kmax)
+        e.set_state(State(np.asarray(pos, np.float64), np.asarray(vel, np.float64), np.full(n, mass, np.float64)))
+        for a0, a1 in zip(edges[:-1], edges[1:]):
+            am = np.sqrt(a0 * a1)
+            e.kdk_step(cosmo.kick_factor(a0, am), cosmo.drift_factor(a0, a1), cosmo.kick_factor(am, a1), eps, _params.G_NEWTON)
+            if callback is not None:
+                callback(float(a1), e)
+        st = e.get_state()
+    return st.pos, st.vel
+
+
+def rebin_like_concept(k_modes, p_modes, half_mode_counts):
+    """Mean k and mean P of consecutive |k|-ordered groups of modes whose sizes are twice `half_mode_counts` — the binning
+    of a CONCEPT power-spectrum table, which lists independent (half-space) mode counts per bin
+    (PPPMP3M/PP/powerspec/powerspec_a=1.00:10-26)."""
+    order = np.argsort(k_modes, kind="stable")
+    k, p = np.asarray(k_modes)[order], np.asarray(p_modes)[order]
+    out_k, out_p, start = [], [], 0
+    for c in half_mode_counts:
+        stop = min(len(k), start + 2 * int(c))
+        if stop <= start:
+            break
+        out_k.append(k[start:stop].mean()); out_p.append(p[start:stop].mean())
+        start = stop
+    return np.array(out_k), np.array(out_p)

@@ -93,6 +93,7 @@ int nb_destroy(nb_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
   nb_bh_release(c);
+  nb_ewald_release(c);
   if (c->state) (void)hipFree(c->state);
   if (c->work) (void)hipFree(c->work);
   if (c->scal) (void)hipFree(c->scal);
@@ -114,11 +115,22 @@ int nb_set_stream(nb_ctx* c, void* hip_stream) {
 
 int nb_set_solver(nb_ctx* c, int solver, double theta) {
   if (!c) return NB_ERR_ARG;
-  if (solver != NB_SOLVER_DIRECT && solver != NB_SOLVER_TREE) return nb_fail(c, NB_ERR_ARG, "nb_set_solver: unknown solver");
+  if (solver != NB_SOLVER_DIRECT && solver != NB_SOLVER_TREE) return nb_fail(c, NB_ERR_ARG, "nb_set_solver: unknown solver (use nb_set_periodic for Ewald)");
   if (solver == NB_SOLVER_TREE && c->dtype != NB_F32) return nb_fail(c, NB_ERR_ARG, "nb_set_solver: the tree solver is fp32 only");
   if (solver == NB_SOLVER_TREE && !(theta >= 0.0 && theta < 2.0)) return nb_fail(c, NB_ERR_ARG, "nb_set_solver: theta must be in [0, 2)");
   if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
   c->solver = solver; c->theta = theta; c->acc_valid = false;
+  return NB_OK;
+}
+
+int nb_set_periodic(nb_ctx* c, double boxsize, double alpha_L, int kmax) {
+  if (!c) return NB_ERR_ARG;
+  if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
+  c->acc_valid = false;
+  if (!(boxsize > 0.0)) { c->solver = NB_SOLVER_DIRECT; c->box = 0.0; return NB_OK; }
+  if (c->dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_set_periodic: the periodic (Ewald) solver is fp64 only");
+  if (!(alpha_L > 0.0) || kmax < 1 || kmax > 16) return nb_fail(c, NB_ERR_ARG, "nb_set_periodic: alpha_L must be > 0 and kmax in [1, 16]");
+  c->solver = NB_SOLVER_EWALD; c->box = boxsize; c->alphaL = alpha_L; c->kmax = kmax;
   return NB_OK;
 }
 
@@ -165,7 +177,13 @@ int nb_get_state(nb_ctx* c, void* x, void* y, void* z, void* vx, void* vy, void*
 // a(x) of the context's own particles into the state's ax/ay/az fields
 static int refresh_acc(nb_ctx* c, double eps, double G) {
   int rc;
-  if (c->solver == NB_SOLVER_TREE) {
+  if (c->solver == NB_SOLVER_EWALD) {
+    if (c->dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "the periodic (Ewald) solver is fp64 only");
+    double* s = reinterpret_cast<double*>(c->state);
+    const size_t n = (size_t)c->n;
+    rc = nb_launch_accel_ewald_f64(c, s, s + n, s + 2 * n, s + 3 * n, c->n, c->box, c->alphaL, c->kmax, eps * eps, G,
+                                   s + 7 * n, s + 8 * n, s + 9 * n);
+  } else if (c->solver == NB_SOLVER_TREE) {
     if (c->dtype != NB_F32) return nb_fail(c, NB_ERR_ARG, "the tree solver is fp32 only");
     float* s = reinterpret_cast<float*>(c->state);
     const size_t n = (size_t)c->n;
@@ -256,9 +274,29 @@ int nb_step(nb_ctx* c, double dt, int64_t nsteps, double eps, double G) {
     // step k: [closing half-kick of step k-1, fused] opening half-kick, drift; force; (closing kick deferred)
     rc = nb_launch_kick_drift(c, c->dtype, x, y, z, vx, vy, vz, ax, ay, az, c->n, k == 0 ? 0.0 : h, h, dt);
     if (rc) return rc;
+    if (c->solver == NB_SOLVER_EWALD) { rc = nb_launch_wrap_f64(c, (double*)x, (double*)y, (double*)z, c->n, c->box); if (rc) return rc; }
     rc = refresh_acc(c, eps, G); if (rc) return rc;
   }
   rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, h); if (rc) return rc;
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  return nb_bh_check(c);
+}
+
+int nb_kdk_step(nb_ctx* c, double kick1, double drift, double kick2, double eps, double G) {
+  if (!c) return NB_ERR_ARG;
+  if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_kdk_step: call nb_set_state first");
+  if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_kdk_step: eps must be >= 0");
+  int rc = use_device(c); if (rc) return rc;
+  if (!c->acc_valid || c->acc_eps != eps || c->acc_G != G) { rc = refresh_acc(c, eps, G); if (rc) return rc; }
+  const size_t b = (size_t)c->n * esize(c->dtype);
+  char* s = reinterpret_cast<char*>(c->state);
+  void *x = s, *y = s + b, *z = s + 2 * b, *vx = s + 4 * b, *vy = s + 5 * b, *vz = s + 6 * b;
+  void *ax = s + 7 * b, *ay = s + 8 * b, *az = s + 9 * b;
+  rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, kick1); if (rc) return rc;
+  rc = nb_launch_drift(c, c->dtype, x, y, z, vx, vy, vz, c->n, drift); if (rc) return rc;
+  if (c->solver == NB_SOLVER_EWALD) { rc = nb_launch_wrap_f64(c, (double*)x, (double*)y, (double*)z, c->n, c->box); if (rc) return rc; }
+  rc = refresh_acc(c, eps, G); if (rc) return rc;
+  rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, kick2); if (rc) return rc;
   NB_HIP(c, hipStreamSynchronize(c->stream));
   return nb_bh_check(c);
 }

@@ -1,0 +1,191 @@
+// Periodic (Ewald) direct summation in a cubic box, fp64 — the force law of CONCEPT's `pp` gravity, which is what the
+// reference's one direct-summation run used (run evidence PPPMP3M/PP/powerspec/powerspec_a=1.00).
+//
+// Textbook Ewald split with a Gaussian of width 1/(2 alpha):
+//   a_i = G sum_j m_j d_ij [ (r^2+eps^2)^{-3/2} - ( erf(alpha r) - (2 alpha r/sqrt(pi)) e^{-alpha^2 r^2} ) / r^3 ]     (minimum image)
+//       - (4 pi G / V) sum_{k != 0} (k/k^2) e^{-k^2/(4 alpha^2)} [ S_c(k) sin(k.x_i) - S_s(k) cos(k.x_i) ]
+//   S_c(k) = sum_j m_j cos(k.x_j),  S_s(k) = sum_j m_j sin(k.x_j),  k = 2 pi n / L,  |n| <= kmax
+// The k = 0 term is dropped = the uniform background is subtracted, as in a cosmological box. With alpha L = 6.2 the real-space
+// term is < 2e-5 of the Newtonian force at the minimum-image boundary r = L/2 and kmax = 7 leaves e^{-k^2/4 alpha^2} < 1e-5.
+//   ewald_real_kernel   all-pairs, LDS-tiled like accel_f64 (sources as (x,y,z,m) in LDS, wave-uniform reads), minimum image
+//                       by x - L rint(x/L); bounded by the fp64 VALU rate (+ erf/exp).
+//   ewald_sk_kernel     one block per k-vector (half space): fixed-order block reduction of m cos / m sin over all particles.
+//   ewald_recip_kernel  one lane per particle: loops over the k-vectors (S_c, S_s, weights in LDS), sincos per (particle, k).
+#include "nb_common.h"
+#include "../../include/nbody_amd.h"
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int BLOCK = 256;
+struct d4 { double x, y, z, w; };
+
+__global__ void __launch_bounds__(BLOCK)
+ewald_real_kernel(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+                  const double* __restrict__ m, int n, double L, double alpha, double eps2, double G,
+                  double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az) {
+  __shared__ d4 tile[BLOCK];
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  const bool live = i < n;
+  const int ic = live ? i : n - 1;
+  const double px = x[ic], py = y[ic], pz = z[ic];
+  const double invL = 1.0 / L;
+  const double two_a_sqrtpi = 2.0 * alpha * 0.5641895835477563;   // 2 alpha / sqrt(pi)
+  double fx = 0.0, fy = 0.0, fz = 0.0;
+  for (int j0 = 0; j0 < n; j0 += BLOCK) {
+    __syncthreads();
+    const int j = j0 + threadIdx.x;
+    const bool ok = j < n;
+    const int jc = ok ? j : n - 1;
+    tile[threadIdx.x] = d4{x[jc], y[jc], z[jc], ok ? m[jc] : 0.0};
+    __syncthreads();
+    const int cnt = min(BLOCK, n - j0);
+    for (int e = 0; e < cnt; ++e) {
+      const d4 s = tile[e];
+      double dx = s.x - px, dy = s.y - py, dz = s.z - pz;
+      dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);   // minimum image
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      if (r2 > 0.0) {
+        const double r = sqrt(r2);
+        const double u = alpha * r;
+        const double rinv = 1.0 / r;
+        const double r2s = r2 + eps2;
+        const double soft = 1.0 / (r2s * sqrt(r2s));
+        const double lng = (erf(u) - two_a_sqrtpi * r * exp(-u * u)) * rinv * rinv * rinv;
+        const double f = s.w * (soft - lng);
+        fx = fma(f, dx, fx); fy = fma(f, dy, fy); fz = fma(f, dz, fz);
+      }
+    }
+  }
+  if (live) { ax[i] = G * fx; ay[i] = G * fy; az[i] = G * fz; }
+}
+
+// kvec[4*q + (0,1,2)] = k vector, [3] = weight = 2 * (4 pi / V) e^{-k^2/4 alpha^2} / k^2   (2 = the mirrored half space)
+__global__ void __launch_bounds__(BLOCK)
+ewald_sk_kernel(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+                const double* __restrict__ m, int n, const double* __restrict__ kvec, double* __restrict__ sk) {
+  const int q = blockIdx.x;
+  const double kx = kvec[4 * q], ky = kvec[4 * q + 1], kz = kvec[4 * q + 2];
+  double sc = 0.0, ss = 0.0;
+  for (int j = threadIdx.x; j < n; j += BLOCK) {
+    double s, c;
+    sincos(kx * x[j] + ky * y[j] + kz * z[j], &s, &c);
+    sc += m[j] * c; ss += m[j] * s;
+  }
+  __shared__ double rc[BLOCK], rs[BLOCK];
+  rc[threadIdx.x] = sc; rs[threadIdx.x] = ss;
+  __syncthreads();
+  for (int w = BLOCK / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { rc[threadIdx.x] += rc[threadIdx.x + w]; rs[threadIdx.x] += rs[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { sk[2 * q] = rc[0]; sk[2 * q + 1] = rs[0]; }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+ewald_recip_kernel(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z, int n,
+                   const double* __restrict__ kvec, const double* __restrict__ sk, int nk, double G,
+                   double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az) {
+  extern __shared__ double lds[];          // [6 * chunk]: kx ky kz w sc ss
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  const bool live = i < n;
+  const int ic = live ? i : n - 1;
+  const double px = x[ic], py = y[ic], pz = z[ic];
+  double fx = 0.0, fy = 0.0, fz = 0.0;
+  constexpr int CH = 256;
+  for (int q0 = 0; q0 < nk; q0 += CH) {
+    __syncthreads();
+    const int q = q0 + threadIdx.x;
+    if (threadIdx.x < CH && q < nk) {
+      lds[6 * threadIdx.x + 0] = kvec[4 * q]; lds[6 * threadIdx.x + 1] = kvec[4 * q + 1]; lds[6 * threadIdx.x + 2] = kvec[4 * q + 2];
+      lds[6 * threadIdx.x + 3] = kvec[4 * q + 3]; lds[6 * threadIdx.x + 4] = sk[2 * q]; lds[6 * threadIdx.x + 5] = sk[2 * q + 1];
+    }
+    __syncthreads();
+    const int cnt = min(CH, nk - q0);
+    for (int e = 0; e < cnt; ++e) {
+      const double kx = lds[6 * e], ky = lds[6 * e + 1], kz = lds[6 * e + 2], w = lds[6 * e + 3];
+      double s, c;
+      sincos(kx * px + ky * py + kz * pz, &s, &c);
+      const double t = -w * (lds[6 * e + 4] * s - lds[6 * e + 5] * c);
+      fx = fma(t, kx, fx); fy = fma(t, ky, fy); fz = fma(t, kz, fz);
+    }
+  }
+  if (live) { ax[i] += G * fx; ay[i] += G * fy; az[i] += G * fz; }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+wrap_kernel(double* __restrict__ x, double* __restrict__ y, double* __restrict__ z, int64_t n, double L) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double v[3] = {x[i], y[i], z[i]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { v[c] -= L * floor(v[c] / L); if (v[c] >= L) v[c] -= L; }
+    x[i] = v[0]; y[i] = v[1]; z[i] = v[2];
+  }
+}
+
+}  // namespace
+
+struct nb_ewald_state {
+  double* kvec = nullptr;   // [4*nk]
+  double* sk = nullptr;     // [2*nk]
+  int nk = 0;
+  double L = 0, alphaL = 0; int kmax = 0;
+};
+
+void nb_ewald_release(nb_ctx* c) {
+  if (c->ewald) {
+    if (c->ewald->kvec) (void)hipFree(c->ewald->kvec);
+    if (c->ewald->sk) (void)hipFree(c->ewald->sk);
+    delete c->ewald; c->ewald = nullptr;
+  }
+}
+
+int nb_launch_wrap_f64(nb_ctx* c, double* x, double* y, double* z, int64_t n, double L) {
+  if (n <= 0) return NB_OK;
+  int64_t b = (n + BLOCK - 1) / BLOCK;
+  wrap_kernel<<<(int)(b > 2048 ? 2048 : b), BLOCK, 0, c->stream>>>(x, y, z, n, L);
+  NB_HIP(c, hipGetLastError());
+  return NB_OK;
+}
+
+int nb_launch_accel_ewald_f64(nb_ctx* c, const double* x, const double* y, const double* z, const double* m, int64_t n,
+                              double L, double alphaL, int kmax, double eps2, double G, double* ax, double* ay, double* az) {
+  if (n <= 0) return NB_OK;
+  if (n >= (1ll << 31)) return nb_fail(c, NB_ERR_ARG, "ewald: n must be < 2^31");
+  if (!(L > 0.0) || !(alphaL > 0.0) || kmax < 1 || kmax > 16) return nb_fail(c, NB_ERR_ARG, "ewald: bad box / alpha / kmax");
+  if (!c->ewald) c->ewald = new nb_ewald_state();
+  nb_ewald_state& e = *c->ewald;
+  const double alpha = alphaL / L;
+  if (e.L != L || e.alphaL != alphaL || e.kmax != kmax) {
+    // k-vector table: half space (first non-zero component positive), |n| <= kmax
+    std::vector<double> kv;
+    const double PI = 3.14159265358979323846, V = L * L * L;
+    for (int a = -kmax; a <= kmax; ++a)
+      for (int b = -kmax; b <= kmax; ++b)
+        for (int d = -kmax; d <= kmax; ++d) {
+          const int n2 = a * a + b * b + d * d;
+          if (n2 == 0 || n2 > kmax * kmax) continue;
+          if (!(a > 0 || (a == 0 && (b > 0 || (b == 0 && d > 0))))) continue;
+          const double kx = 2 * PI * a / L, ky = 2 * PI * b / L, kz = 2 * PI * d / L, k2 = kx * kx + ky * ky + kz * kz;
+          kv.push_back(kx); kv.push_back(ky); kv.push_back(kz);
+          kv.push_back(2.0 * (4.0 * PI / V) * std::exp(-k2 / (4.0 * alpha * alpha)) / k2);
+        }
+    NB_HIP(c, hipStreamSynchronize(c->stream));
+    if (e.kvec) { NB_HIP(c, hipFree(e.kvec)); e.kvec = nullptr; }
+    if (e.sk) { NB_HIP(c, hipFree(e.sk)); e.sk = nullptr; }
+    e.nk = (int)(kv.size() / 4);
+    NB_HIP(c, hipMalloc((void**)&e.kvec, kv.size() * sizeof(double)));
+    NB_HIP(c, hipMalloc((void**)&e.sk, 2 * (size_t)e.nk * sizeof(double)));
+    NB_HIP(c, hipMemcpy(e.kvec, kv.data(), kv.size() * sizeof(double), hipMemcpyHostToDevice));
+    e.L = L; e.alphaL = alphaL; e.kmax = kmax;
+  }
+  const int nb = (int)((n + BLOCK - 1) / BLOCK);
+  ewald_real_kernel<<<nb, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, L, alpha, eps2, G, ax, ay, az);
+  NB_HIP(c, hipGetLastError());
+  ewald_sk_kernel<<<e.nk, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, e.kvec, e.sk);
+  NB_HIP(c, hipGetLastError());
+  ewald_recip_kernel<<<nb, BLOCK, 6 * 256 * sizeof(double), c->stream>>>(x, y, z, (int)n, e.kvec, e.sk, e.nk, G, ax, ay, az);
+  NB_HIP(c, hipGetLastError());
+  return NB_OK;
+}

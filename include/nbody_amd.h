@@ -36,7 +36,7 @@ typedef struct nb_ctx nb_ctx;
 
 enum { NB_F32 = 0, NB_F64 = 1 };
 /* force solvers selectable per context (nb_set_solver) */
-enum { NB_SOLVER_DIRECT = 0, NB_SOLVER_TREE = 1 };
+enum { NB_SOLVER_DIRECT = 0, NB_SOLVER_TREE = 1, NB_SOLVER_EWALD = 2 };
 /* flags of nb_accel_dev */
 enum {
   NB_ACCUMULATE = 1,   /* add to the existing ax/ay/az instead of overwriting (source chunks arriving hop by hop) */
@@ -66,6 +66,14 @@ int nb_synchronize(nb_ctx* ctx);
  * Barnes-Hut with opening angle theta (BASELINE.json configs[4]; fp32 contexts only; theta = 0 degenerates to the
  * direct sum) */
 int nb_set_solver(nb_ctx* ctx, int solver, double theta);
+/* periodic cubic box of edge `boxsize`: nb_accel / nb_step / nb_kdk_step use Ewald summation (minimum-image real-space sum +
+ * reciprocal sum over |n| <= kmax, splitting alpha = alpha_L / boxsize; uniform background subtracted) — the force law of the
+ * CONCEPT `pp` run behind PPPMP3M/PP/powerspec/powerspec_a=1.00. fp64 contexts only; positions are wrapped into [0, boxsize)
+ * after every drift. boxsize <= 0 returns to the isolated direct sum. Suggested alpha_L = 6.2, kmax = 7 (error ~1e-5). */
+int nb_set_periodic(nb_ctx* ctx, double boxsize, double alpha_L, int kmax);
+/* one generalised KDK step: v += a*kick1; x += v*drift; a = a(x); v += a*kick2 — with kick = integral dt/a and
+ * drift = integral dt/a^2 this is the comoving leapfrog of a cosmological run (v = canonical momentum per unit mass) */
+int nb_kdk_step(nb_ctx* ctx, double kick1, double drift, double kick2, double eps, double G);
 
 /* ---- host-pointer surface: the drop-in compute_forces()/step()/energy() (SURVEY §8a ⊕1-⊕3) ---- */
 int nb_set_state(nb_ctx* ctx, const void* x, const void* y, const void* z,
