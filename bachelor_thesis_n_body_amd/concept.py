@@ -35,6 +35,41 @@ def _write_powerspec(path: Path, k, pk, counts, a: float, ngrid: int) -> None:
             fh.write(f"{ki:.7e} {int(ci):6d}  {pi:.7e}\n")
 
 
+def _run_cosmological(args, p, s) -> int:
+    """CONCEPT-like run: Zel'dovich ICs at a_begin from the linear P(k) table (at a = 1), comoving KDK with periodic Ewald
+    forces up to the last requested scale factor, snapshot (+ power spectrum) at every requested output time."""
+    from . import cosmo, field, snapshot
+    L = s["boxsize"]
+    n_side = round(s["N"] ** (1.0 / 3.0))
+    if n_side ** 3 != s["N"] or not args.pk_table or not p.get("H0"):
+        print("concept: --cosmological needs N = n^3, --pk-table (linear P(k) at a = 1) and H0/Ωb/Ωcdm in the parameter file", file=sys.stderr)
+        return 2
+    h = float(p["H0"]) / (100 * _params.UNITS["km"] / _params.UNITS["s"])
+    c = cosmo.Cosmology(float(p["H0"]), float(p["Ωb"]) + float(p["Ωcdm"]), (2.473e-5 * (1.0 + 0.2271 * 3.046)) / h ** 2)
+    seeds = s["random_seeds"]
+    a0 = s["a_begin"]
+    pos, vel = cosmo.zeldovich_ics(np.loadtxt(args.pk_table), n_side, L, c, a0, int(seeds.get("primordial amplitudes", 0)),
+                                   int(seeds.get("primordial phases", 1)))
+    mass = c.particle_mass(L, n_side ** 3)
+    outs = sorted(set(t for t in (s["snapshot_times"] or [1.0]) if t > a0))
+    out = Path(s["snapshot_dir"])
+    out.mkdir(parents=True, exist_ok=True)
+    nsteps = args.steps if args.steps > 0 else 400
+    total = np.log(outs[-1] / a0)
+    for a1 in outs:
+        k = max(1, round(nsteps * np.log(a1 / a0) / total))
+        pos, vel = cosmo.run_pp(pos, vel, mass, L, c, a0, a1, nsteps=k, eps=args.eps)
+        snapshot.write_snapshot(str(out / f"snapshot_a={a1:.2f}.hdf5"), pos, vel * mass, L, mass=mass,
+                                extra_attrs={"a": float(a1), "H0": float(p["H0"])})
+        if s["powerspec_dir"]:
+            pdir = Path(s["powerspec_dir"]); pdir.mkdir(parents=True, exist_ok=True)
+            kk, pk, cnt = field.power_spectrum(pos, L, n_side, deconvolve=True)
+            _write_powerspec(pdir / f"powerspec_a={a1:.2f}", kk, pk, cnt, a1, n_side)
+        a0 = a1
+    print(f"concept: cosmological pp run finished at a = {a0:g}; {len(outs)} snapshot(s) in {out}")
+    return 0
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="concept", description=__doc__.split("\n\n")[0])
     ap.add_argument("-p", "--param", required=True)
@@ -49,6 +84,9 @@ def main(argv=None) -> int:
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f64")
     ap.add_argument("--solver", choices=["direct", "tree"], default="direct")
     ap.add_argument("--theta", type=float, default=0.5)
+    ap.add_argument("--cosmological", action="store_true",
+                    help="comoving integration from a_begin to the largest output time in a periodic box (Ewald forces, fp64): "
+                         "the physics of a CONCEPT `pp` run; --steps counts steps uniform in ln a (default 400)")
     args = ap.parse_args(argv)
 
     try:
@@ -70,6 +108,8 @@ def main(argv=None) -> int:
     from . import Engine, State, field, grf, snapshot   # needs the HIP library from here on
 
     L = s["boxsize"]
+    if args.cosmological:
+        return _run_cosmological(args, p, s)
     ic_file = args.ic or s["ic_file"]
     if ic_file:
         pos = snapshot.read_positions(ic_file)

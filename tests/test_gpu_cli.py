@@ -28,3 +28,23 @@ def test_cli_generates_ics_runs_and_writes_outputs(tmp_path):
     # restart from the written snapshot (initial_conditions by file), tree solver, fp32
     rc = concept.main(["-p", str(f), "--ic", str(snaps[0]), "--steps", "2", "--dtype", "f32", "--solver", "tree"])
     assert rc == 0
+
+
+def test_cli_cosmological_run(tmp_path):
+    """`--cosmological`: the CONCEPT-like path (comoving, periodic) from the same parameter file."""
+    k = np.logspace(-3, 1, 200)
+    np.savetxt(tmp_path / "pk.txt", np.column_stack([k, 2.0e4 * (k / 0.02) / (1 + (k / 0.02) ** 2) ** 1.6]))
+    f = _write(tmp_path)
+    rc = concept.main(["-p", str(f), "-n", "1", "--local", "--cosmological", "--pk-table", str(tmp_path / "pk.txt"), "--steps", "30",
+                       "-c", "output_times = {'snapshot': [0.1, 1.0]}"])
+    assert rc == 0
+    snaps = sorted((tmp_path / "output").rglob("snapshot_a=*.hdf5"))
+    assert [s.name for s in snaps] == ["snapshot_a=0.10.hdf5", "snapshot_a=1.00.hdf5"]
+    early, late = sn.read_positions(str(snaps[0])), sn.read_positions(str(snaps[1]))
+    assert early.shape == late.shape == (512, 3) and late.min() >= 0 and late.max() < 500.0
+    assert sn.read_attrs(str(snaps[1]))["a"] == 1.0
+    # structure grows: displacements from the lattice at a = 1 exceed those at a = 0.1
+    g = np.linspace(0, 500.0, 8, endpoint=False)
+    q = np.array(np.meshgrid(g, g, g, indexing="ij")).reshape(3, -1).T
+    disp = lambda x: np.abs((x - q + 250.0) % 500.0 - 250.0).mean()
+    assert disp(late) > 3 * disp(early)
