@@ -73,7 +73,7 @@ class Engine:
         _lib.check(self._ctx, self._lib.nb_set_solver(self._ctx, code, float(theta)), "nb_set_solver")
 
     def set_periodic(self, boxsize: float, alpha_L: float = 6.2, kmax: int = 7) -> None:
-        """Cubic periodic box (Ewald summation, uniform background subtracted); boxsize <= 0 switches it off. fp64 only."""
+        """Cubic periodic box (Ewald summation, uniform background subtracted); boxsize <= 0 switches it off."""
         _lib.check(self._ctx, self._lib.nb_set_periodic(self._ctx, float(boxsize), float(alpha_L), int(kmax)), "nb_set_periodic")
 
     def kdk_step(self, kick1: float, drift: float, kick2: float, eps: float, G: float = 1.0) -> None:

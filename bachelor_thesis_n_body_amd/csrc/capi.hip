@@ -128,7 +128,6 @@ int nb_set_periodic(nb_ctx* c, double boxsize, double alpha_L, int kmax) {
   if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
   c->acc_valid = false;
   if (!(boxsize > 0.0)) { c->solver = NB_SOLVER_DIRECT; c->box = 0.0; return NB_OK; }
-  if (c->dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_set_periodic: the periodic (Ewald) solver is fp64 only");
   if (!(alpha_L > 0.0) || kmax < 1 || kmax > 16) return nb_fail(c, NB_ERR_ARG, "nb_set_periodic: alpha_L must be > 0 and kmax in [1, 16]");
   c->solver = NB_SOLVER_EWALD; c->box = boxsize; c->alphaL = alpha_L; c->kmax = kmax;
   return NB_OK;
@@ -178,11 +177,10 @@ int nb_get_state(nb_ctx* c, void* x, void* y, void* z, void* vx, void* vy, void*
 static int refresh_acc(nb_ctx* c, double eps, double G) {
   int rc;
   if (c->solver == NB_SOLVER_EWALD) {
-    if (c->dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "the periodic (Ewald) solver is fp64 only");
-    double* s = reinterpret_cast<double*>(c->state);
-    const size_t n = (size_t)c->n;
-    rc = nb_launch_accel_ewald_f64(c, s, s + n, s + 2 * n, s + 3 * n, c->n, c->box, c->alphaL, c->kmax, eps * eps, G,
-                                   s + 7 * n, s + 8 * n, s + 9 * n);
+    const size_t b = (size_t)c->n * esize(c->dtype);
+    char* s = reinterpret_cast<char*>(c->state);
+    rc = nb_launch_accel_ewald(c, c->dtype, s, s + b, s + 2 * b, s + 3 * b, c->n, c->box, c->alphaL, c->kmax, eps * eps, G,
+                               s + 7 * b, s + 8 * b, s + 9 * b);
   } else if (c->solver == NB_SOLVER_TREE) {
     if (c->dtype != NB_F32) return nb_fail(c, NB_ERR_ARG, "the tree solver is fp32 only");
     float* s = reinterpret_cast<float*>(c->state);
@@ -274,7 +272,7 @@ int nb_step(nb_ctx* c, double dt, int64_t nsteps, double eps, double G) {
     // step k: [closing half-kick of step k-1, fused] opening half-kick, drift; force; (closing kick deferred)
     rc = nb_launch_kick_drift(c, c->dtype, x, y, z, vx, vy, vz, ax, ay, az, c->n, k == 0 ? 0.0 : h, h, dt);
     if (rc) return rc;
-    if (c->solver == NB_SOLVER_EWALD) { rc = nb_launch_wrap_f64(c, (double*)x, (double*)y, (double*)z, c->n, c->box); if (rc) return rc; }
+    if (c->solver == NB_SOLVER_EWALD) { rc = nb_launch_wrap(c, c->dtype, x, y, z, c->n, c->box); if (rc) return rc; }
     rc = refresh_acc(c, eps, G); if (rc) return rc;
   }
   rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, h); if (rc) return rc;
@@ -294,7 +292,7 @@ int nb_kdk_step(nb_ctx* c, double kick1, double drift, double kick2, double eps,
   void *ax = s + 7 * b, *ay = s + 8 * b, *az = s + 9 * b;
   rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, kick1); if (rc) return rc;
   rc = nb_launch_drift(c, c->dtype, x, y, z, vx, vy, vz, c->n, drift); if (rc) return rc;
-  if (c->solver == NB_SOLVER_EWALD) { rc = nb_launch_wrap_f64(c, (double*)x, (double*)y, (double*)z, c->n, c->box); if (rc) return rc; }
+  if (c->solver == NB_SOLVER_EWALD) { rc = nb_launch_wrap(c, c->dtype, x, y, z, c->n, c->box); if (rc) return rc; }
   rc = refresh_acc(c, eps, G); if (rc) return rc;
   rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, kick2); if (rc) return rc;
   NB_HIP(c, hipStreamSynchronize(c->stream));

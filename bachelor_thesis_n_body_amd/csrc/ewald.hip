@@ -1,4 +1,4 @@
-// Periodic (Ewald) direct summation in a cubic box, fp64 — the force law of CONCEPT's `pp` gravity, which is what the
+// Periodic (Ewald) direct summation in a cubic box, fp64 and fp32 — the force law of CONCEPT's `pp` gravity, which is what the
 // reference's one direct-summation run used (run evidence PPPMP3M/PP/powerspec/powerspec_a=1.00).
 //
 // Textbook Ewald split with a Gaussian of width 1/(2 alpha):
@@ -61,17 +61,68 @@ ewald_real_kernel(const double* __restrict__ x, const double* __restrict__ y, co
   if (live) { ax[i] = G * fx; ay[i] = G * fy; az[i] = G * fz; }
 }
 
-// kvec[4*q + (0,1,2)] = k vector, [3] = weight = 2 * (4 pi / V) e^{-k^2/4 alpha^2} / k^2   (2 = the mirrored half space)
+// fp32 version of the real-space sum: v_rsq / v_exp / v_rcp transcendentals, erfc by Abramowitz-Stegun 7.1.26
+// (|error| < 1.5e-7, i.e. 1.5e-7 of the local Newtonian pair force), fp32 partial sums flushed to fp64 per source tile as
+// in accel_f32.hip. ~45 full-rate VALU + 4 transcendentals per interaction.
 __global__ void __launch_bounds__(BLOCK)
-ewald_sk_kernel(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
-                const double* __restrict__ m, int n, const double* __restrict__ kvec, double* __restrict__ sk) {
+ewald_real_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                      const float* __restrict__ m, int n, float L, float alpha, float eps2, float G,
+                      float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az) {
+  __shared__ float4 tile[BLOCK];
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  const bool live = i < n;
+  const int ic = live ? i : n - 1;
+  const float px = x[ic], py = y[ic], pz = z[ic];
+  const float invL = 1.0f / L;
+  const float c2 = 2.0f * alpha * 0.5641895835f;        // 2 alpha / sqrt(pi)
+  const float a2l = -alpha * alpha * 1.4426950409f;     // -alpha^2 log2(e)
+  double tx = 0.0, ty = 0.0, tz = 0.0;
+  for (int j0 = 0; j0 < n; j0 += BLOCK) {
+    __syncthreads();
+    const int j = j0 + threadIdx.x;
+    const bool ok = j < n;
+    const int jc = ok ? j : n - 1;
+    tile[threadIdx.x] = make_float4(x[jc], y[jc], z[jc], ok ? m[jc] : 0.0f);
+    __syncthreads();
+    const int cnt = min(BLOCK, n - j0);
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+#pragma unroll 4
+    for (int e = 0; e < cnt; ++e) {
+      const float4 s = tile[e];
+      float dx = s.x - px, dy = s.y - py, dz = s.z - pz;
+      dx = fmaf(-L, rintf(dx * invL), dx); dy = fmaf(-L, rintf(dy * invL), dy); dz = fmaf(-L, rintf(dz * invL), dz);
+      const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+      const float rinv = r2 > 0.f ? __builtin_amdgcn_rsqf(r2) : 0.f;       // self / coincident: no contribution
+      const float r = r2 * rinv;
+      const float u = alpha * r;
+      const float t = __builtin_amdgcn_exp2f(a2l * r2);                    // e^{-alpha^2 r^2}
+      const float q = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+      const float poly = q * fmaf(q, fmaf(q, fmaf(q, fmaf(q, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+      const float erf_u = fmaf(-poly, t, 1.0f);                            // 1 - erfc(u)
+      const float rinv3 = rinv * rinv * rinv;
+      const float lng = (erf_u - c2 * r * t) * rinv3;
+      const float sinv = __builtin_amdgcn_rsqf(r2 + eps2);
+      const float soft = r2 > 0.f ? sinv * sinv * sinv : 0.f;
+      const float f = s.w * (soft - lng);
+      fx = fmaf(f, dx, fx); fy = fmaf(f, dy, fy); fz = fmaf(f, dz, fz);
+    }
+    tx += (double)fx; ty += (double)fy; tz += (double)fz;
+  }
+  if (live) { ax[i] = (float)((double)G * tx); ay[i] = (float)((double)G * ty); az[i] = (float)((double)G * tz); }
+}
+
+// kvec[4*q + (0,1,2)] = k vector, [3] = weight = 2 * (4 pi / V) e^{-k^2/4 alpha^2} / k^2   (2 = the mirrored half space)
+template <typename T>
+__global__ void __launch_bounds__(BLOCK)
+ewald_sk_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z,
+                const T* __restrict__ m, int n, const double* __restrict__ kvec, double* __restrict__ sk) {
   const int q = blockIdx.x;
   const double kx = kvec[4 * q], ky = kvec[4 * q + 1], kz = kvec[4 * q + 2];
   double sc = 0.0, ss = 0.0;
   for (int j = threadIdx.x; j < n; j += BLOCK) {
     double s, c;
-    sincos(kx * x[j] + ky * y[j] + kz * z[j], &s, &c);
-    sc += m[j] * c; ss += m[j] * s;
+    sincos(kx * (double)x[j] + ky * (double)y[j] + kz * (double)z[j], &s, &c);
+    sc += (double)m[j] * c; ss += (double)m[j] * s;
   }
   __shared__ double rc[BLOCK], rs[BLOCK];
   rc[threadIdx.x] = sc; rs[threadIdx.x] = ss;
@@ -83,15 +134,16 @@ ewald_sk_kernel(const double* __restrict__ x, const double* __restrict__ y, cons
   if (threadIdx.x == 0) { sk[2 * q] = rc[0]; sk[2 * q + 1] = rs[0]; }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(BLOCK)
-ewald_recip_kernel(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z, int n,
+ewald_recip_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, int n,
                    const double* __restrict__ kvec, const double* __restrict__ sk, int nk, double G,
-                   double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az) {
+                   T* __restrict__ ax, T* __restrict__ ay, T* __restrict__ az) {
   extern __shared__ double lds[];          // [6 * chunk]: kx ky kz w sc ss
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   const bool live = i < n;
   const int ic = live ? i : n - 1;
-  const double px = x[ic], py = y[ic], pz = z[ic];
+  const double px = (double)x[ic], py = (double)y[ic], pz = (double)z[ic];
   double fx = 0.0, fy = 0.0, fz = 0.0;
   constexpr int CH = 256;
   for (int q0 = 0; q0 < nk; q0 += CH) {
@@ -111,15 +163,16 @@ ewald_recip_kernel(const double* __restrict__ x, const double* __restrict__ y, c
       fx = fma(t, kx, fx); fy = fma(t, ky, fy); fz = fma(t, kz, fz);
     }
   }
-  if (live) { ax[i] += G * fx; ay[i] += G * fy; az[i] += G * fz; }
+  if (live) { ax[i] = (T)((double)ax[i] + G * fx); ay[i] = (T)((double)ay[i] + G * fy); az[i] = (T)((double)az[i] + G * fz); }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(BLOCK)
-wrap_kernel(double* __restrict__ x, double* __restrict__ y, double* __restrict__ z, int64_t n, double L) {
+wrap_kernel(T* __restrict__ x, T* __restrict__ y, T* __restrict__ z, int64_t n, T L) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double v[3] = {x[i], y[i], z[i]};
+    T v[3] = {x[i], y[i], z[i]};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { v[c] -= L * floor(v[c] / L); if (v[c] >= L) v[c] -= L; }
+    for (int c = 0; c < 3; ++c) { v[c] -= L * floor(v[c] / L); if (v[c] >= L) v[c] -= L; if (v[c] < (T)0) v[c] = (T)0; }
     x[i] = v[0]; y[i] = v[1]; z[i] = v[2];
   }
 }
@@ -141,16 +194,18 @@ void nb_ewald_release(nb_ctx* c) {
   }
 }
 
-int nb_launch_wrap_f64(nb_ctx* c, double* x, double* y, double* z, int64_t n, double L) {
+int nb_launch_wrap(nb_ctx* c, int dtype, void* x, void* y, void* z, int64_t n, double L) {
   if (n <= 0) return NB_OK;
   int64_t b = (n + BLOCK - 1) / BLOCK;
-  wrap_kernel<<<(int)(b > 2048 ? 2048 : b), BLOCK, 0, c->stream>>>(x, y, z, n, L);
+  const int g = (int)(b > 2048 ? 2048 : b);
+  if (dtype == NB_F32) wrap_kernel<float><<<g, BLOCK, 0, c->stream>>>((float*)x, (float*)y, (float*)z, n, (float)L);
+  else wrap_kernel<double><<<g, BLOCK, 0, c->stream>>>((double*)x, (double*)y, (double*)z, n, L);
   NB_HIP(c, hipGetLastError());
   return NB_OK;
 }
 
-int nb_launch_accel_ewald_f64(nb_ctx* c, const double* x, const double* y, const double* z, const double* m, int64_t n,
-                              double L, double alphaL, int kmax, double eps2, double G, double* ax, double* ay, double* az) {
+int nb_launch_accel_ewald(nb_ctx* c, int dtype, const void* x, const void* y, const void* z, const void* m, int64_t n,
+                          double L, double alphaL, int kmax, double eps2, double G, void* ax, void* ay, void* az) {
   if (n <= 0) return NB_OK;
   if (n >= (1ll << 31)) return nb_fail(c, NB_ERR_ARG, "ewald: n must be < 2^31");
   if (!(L > 0.0) || !(alphaL > 0.0) || kmax < 1 || kmax > 16) return nb_fail(c, NB_ERR_ARG, "ewald: bad box / alpha / kmax");
@@ -181,11 +236,23 @@ int nb_launch_accel_ewald_f64(nb_ctx* c, const double* x, const double* y, const
     e.L = L; e.alphaL = alphaL; e.kmax = kmax;
   }
   const int nb = (int)((n + BLOCK - 1) / BLOCK);
-  ewald_real_kernel<<<nb, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, L, alpha, eps2, G, ax, ay, az);
-  NB_HIP(c, hipGetLastError());
-  ewald_sk_kernel<<<e.nk, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, e.kvec, e.sk);
-  NB_HIP(c, hipGetLastError());
-  ewald_recip_kernel<<<nb, BLOCK, 6 * 256 * sizeof(double), c->stream>>>(x, y, z, (int)n, e.kvec, e.sk, e.nk, G, ax, ay, az);
+  const size_t lds = 6 * 256 * sizeof(double);
+  if (dtype == NB_F32) {
+    const float *fx = (const float*)x, *fy = (const float*)y, *fz = (const float*)z, *fm = (const float*)m;
+    ewald_real_f32_kernel<<<nb, BLOCK, 0, c->stream>>>(fx, fy, fz, fm, (int)n, (float)L, (float)alpha, (float)eps2, (float)G,
+                                                       (float*)ax, (float*)ay, (float*)az);
+    NB_HIP(c, hipGetLastError());
+    ewald_sk_kernel<float><<<e.nk, BLOCK, 0, c->stream>>>(fx, fy, fz, fm, (int)n, e.kvec, e.sk);
+    NB_HIP(c, hipGetLastError());
+    ewald_recip_kernel<float><<<nb, BLOCK, lds, c->stream>>>(fx, fy, fz, (int)n, e.kvec, e.sk, e.nk, G, (float*)ax, (float*)ay, (float*)az);
+  } else {
+    const double *dx = (const double*)x, *dy = (const double*)y, *dz = (const double*)z, *dm = (const double*)m;
+    ewald_real_kernel<<<nb, BLOCK, 0, c->stream>>>(dx, dy, dz, dm, (int)n, L, alpha, eps2, G, (double*)ax, (double*)ay, (double*)az);
+    NB_HIP(c, hipGetLastError());
+    ewald_sk_kernel<double><<<e.nk, BLOCK, 0, c->stream>>>(dx, dy, dz, dm, (int)n, e.kvec, e.sk);
+    NB_HIP(c, hipGetLastError());
+    ewald_recip_kernel<double><<<nb, BLOCK, lds, c->stream>>>(dx, dy, dz, (int)n, e.kvec, e.sk, e.nk, G, (double*)ax, (double*)ay, (double*)az);
+  }
   NB_HIP(c, hipGetLastError());
   return NB_OK;
 }

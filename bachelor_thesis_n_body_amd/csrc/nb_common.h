@@ -58,10 +58,10 @@ int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const dou
 // Barnes-Hut acceleration of n particles on themselves (fp32); falls back to the direct sum for n < 128 or theta <= 0
 int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
                              float eps2, float G, float theta, float* ax, float* ay, float* az);
-// periodic Ewald summation (fp64): acceleration of all n particles on themselves, uniform background subtracted
-int nb_launch_accel_ewald_f64(nb_ctx* c, const double* x, const double* y, const double* z, const double* m, int64_t n,
-                              double L, double alphaL, int kmax, double eps2, double G, double* ax, double* ay, double* az);
-int nb_launch_wrap_f64(nb_ctx* c, double* x, double* y, double* z, int64_t n, double L);
+// periodic Ewald summation: acceleration of all n particles on themselves, uniform background subtracted
+int nb_launch_accel_ewald(nb_ctx* c, int dtype, const void* x, const void* y, const void* z, const void* m, int64_t n,
+                          double L, double alphaL, int kmax, double eps2, double G, void* ax, void* ay, void* az);
+int nb_launch_wrap(nb_ctx* c, int dtype, void* x, void* y, void* z, int64_t n, double L);
 void nb_ewald_release(nb_ctx* c);
 void nb_bh_release(nb_ctx* c);
 int nb_bh_check(nb_ctx* c);   // call after a stream sync

@@ -68,7 +68,8 @@ int nb_synchronize(nb_ctx* ctx);
 int nb_set_solver(nb_ctx* ctx, int solver, double theta);
 /* periodic cubic box of edge `boxsize`: nb_accel / nb_step / nb_kdk_step use Ewald summation (minimum-image real-space sum +
  * reciprocal sum over |n| <= kmax, splitting alpha = alpha_L / boxsize; uniform background subtracted) — the force law of the
- * CONCEPT `pp` run behind PPPMP3M/PP/powerspec/powerspec_a=1.00. fp64 contexts only; positions are wrapped into [0, boxsize)
+ * CONCEPT `pp` run behind PPPMP3M/PP/powerspec/powerspec_a=1.00. fp64 contexts use erf/exp in fp64; fp32 contexts a 1.5e-7
+ * erfc approximation with fp64-flushed fp32 sums (~5x faster). Positions are wrapped into [0, boxsize)
  * after every drift. boxsize <= 0 returns to the isolated direct sum. Suggested alpha_L = 6.2, kmax = 7 (error ~1e-5). */
 int nb_set_periodic(nb_ctx* ctx, double boxsize, double alpha_L, int kmax);
 /* one generalised KDK step: v += a*kick1; x += v*drift; a = a(x); v += a*kick2 — with kick = integral dt/a and

@@ -63,9 +63,22 @@ def test_comoving_kdk_step_matches_oracle_and_wraps_positions():
     np.testing.assert_allclose(st.pos, x, rtol=0, atol=1e-10)
     np.testing.assert_allclose(st.vel, v, rtol=1e-9, atol=1e-12)
     assert st.pos.min() >= 0 and st.pos.max() < L
-    with nb.Engine(8, np.float32) as e:
-        with pytest.raises(RuntimeError, match="fp64 only"):
-            e.set_periodic(10.0)
+
+
+@pytest.mark.parametrize("n,L,eps", [(500, 50.0, 0.2), (4000, 500.0, 0.25)])
+def test_ewald_fp32_kernel_matches_oracle(n, L, eps):
+    """fp32 contexts: erfc by a 1.5e-7 rational approximation, fp32 sums flushed to fp64 — 2e-5 of the largest force
+    (the Ewald truncation itself is 3e-5)."""
+    rng = np.random.default_rng(n)
+    pos, m = rng.uniform(0, L, (n, 3)).astype(np.float32), rng.uniform(0.5, 2.0, n).astype(np.float32)
+    with nb.Engine(n, np.float32) as e:
+        e.set_periodic(L)
+        e.set_state(nb.State(pos, np.zeros_like(pos), m))
+        a = e.accel(eps, 2.0)
+    ref = eo.ewald_accel(pos.astype(np.float64), m.astype(np.float64), L, eps, G=2.0, alpha_L=6.2, kmax=7, images=0)
+    assert a.dtype == np.float32
+    assert np.abs(a - ref).max() < 2e-5 * np.abs(ref).max()
+    assert np.median(np.linalg.norm(a - ref, axis=1) / np.linalg.norm(ref, axis=1)) < 2e-6
 
 
 def test_linear_growth_of_a_zeldovich_field():

@@ -12,6 +12,7 @@ from bachelor_thesis_n_body_amd import cosmo, field
 nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 n_side = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+dtype = np.float32 if (len(sys.argv) > 4 and sys.argv[4] == "f32") else np.float64
 L, a_begin = 500.0, 0.02
 ref = np.loadtxt(os.path.join(ROOT, "tests", "golden", "concept", "PP_powerspec_a=1.00"))
 k_ref, modes, p_ref, p_lin = ref[:, 0], ref[:, 1].astype(int), ref[:, 2], ref[:, 4]
@@ -23,7 +24,7 @@ c = cosmo.Cosmology.from_h_omegas(0.6736, 0.02237, 0.12)
 t0 = time.perf_counter()
 pos, vel = cosmo.zeldovich_ics(tab, n_side, L, c, a_begin, seed, seed + 1000)
 mass = c.particle_mass(L, n_side ** 3)
-pos, vel = cosmo.run_pp(pos, vel, mass, L, c, a_begin, 1.0, nsteps)
+pos, vel = cosmo.run_pp(pos, vel, mass, L, c, a_begin, 1.0, nsteps, dtype=dtype)
 t_run = time.perf_counter() - t0
 with field.FieldPlan(n_side, L) as plan:           # CIC + deconvolution on the GPU, per-mode power on the host
     plan.cic(pos); plan.affine(plan.mean(), 1.0, 1.0); plan.deconvolve()
@@ -35,10 +36,10 @@ kmag = np.sqrt(kx ** 2 + ky ** 2 + kz ** 2).ravel()
 pk = (np.abs(dk) ** 2 * L ** 3 / n_side ** 6).ravel()
 sel = kmag > 0
 k_b, p_b = cosmo.rebin_like_concept(kmag[sel], pk[sel], modes if n_side == 64 else modes[: max(2, len(modes) // 2)])
-print(f"# {n_side}^3 particles, {nsteps} steps in ln a, wall {t_run:.1f} s (CONCEPT: 257257 s)")
+print(f"# {n_side}^3 particles, {nsteps} steps in ln a, {np.dtype(dtype).name} forces, wall {t_run:.1f} s (CONCEPT: 257257 s)")
 print("#  k_ref      k_here     modes   P_ref        P_here       ratio   P_ref/P_lin  P_here/P_lin")
 for i in range(len(k_b)):
     print(f"{k_ref[i]:.4e} {k_b[i]:.4e} {modes[i]:6d}  {p_ref[i]:.4e}  {p_b[i]:.4e}  {p_b[i]/p_ref[i]:6.3f}   {p_ref[i]/p_lin[i]:6.3f}      {p_b[i]/p_lin[i]:6.3f}")
 r = p_b / p_ref[: len(p_b)]
-print(json.dumps({"n_side": n_side, "nsteps": nsteps, "wall_s": t_run, "ratio_mean_bins_4_16": float(r[3:].mean()),
+print(json.dumps({"n_side": n_side, "nsteps": nsteps, "dtype": np.dtype(dtype).name, "wall_s": t_run, "ratio_mean_bins_4_16": float(r[3:].mean()),
                   "ratio_min": float(r.min()), "ratio_max": float(r.max()), "reference_wall_s": 257257}))
