@@ -112,6 +112,31 @@ def run_pp(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: flo
     return st.pos.astype(np.float64), st.vel.astype(np.float64)
 
 
+def power_modes(pos, boxsize: float, ngrid: int, interlace: bool = True):
+    """Per-mode (|k|, P) of the CIC-deposited, window-deconvolved overdensity, optionally INTERLACED (two grids half a
+    cell apart combined in k-space, which cancels the odd aliases) — CONCEPT's estimator settings in NN.param:30-41
+    ('interpolation': 'CIC', 'deconvolve': True, 'interlace': True). The thesis' own estimator (Power_compare.py) does not
+    interlace; `field.power_spectrum` mirrors that one. Deposit on the GPU, FFT of the ngrid^3 field on the host."""
+    from . import field
+    h = boxsize / ngrid
+    with field.FieldPlan(ngrid, boxsize) as plan:
+        plan.cic(pos); plan.affine(plan.mean(), 1.0, 1.0)
+        d1 = np.fft.fftn(plan.get())
+        if interlace:
+            plan.cic(np.mod(np.asarray(pos, np.float64) - 0.5 * h, boxsize)); plan.affine(plan.mean(), 1.0, 1.0)
+            d2 = np.fft.fftn(plan.get())
+    kv = 2 * np.pi * np.fft.fftfreq(ngrid, d=h)
+    kx, ky, kz = np.meshgrid(kv, kv, kv, indexing="ij")
+    if interlace:
+        d1 = 0.5 * (d1 + np.exp(-0.5j * h * (kx + ky + kz)) * d2)
+    w = np.sinc(kv * h / (2 * np.pi))                      # CIC window per axis: sinc^2
+    W = (w[:, None, None] * w[None, :, None] * w[None, None, :]) ** 2
+    pk = np.abs(d1 / W) ** 2 * boxsize ** 3 / ngrid ** 6
+    kmag = np.sqrt(kx ** 2 + ky ** 2 + kz ** 2)
+    sel = kmag > 0
+    return kmag[sel], pk[sel]
+
+
 def rebin_like_concept(k_modes, p_modes, half_mode_counts):
     """Mean k and mean P of consecutive |k|-ordered groups of modes whose sizes are twice `half_mode_counts` — the binning
     of a CONCEPT power-spectrum table, which lists independent (half-space) mode counts per bin

@@ -99,5 +99,5 @@ def test_plan_reuse_and_engine_state_roundtrip(tmp_path):
         c = plan.delta_field(sn.read_positions(str(out)))
     np.testing.assert_allclose(a, fo.delta_field(pos, box, 32, False), rtol=1e-11, atol=1e-11)   # peak delta ~ 40 here
     np.testing.assert_allclose(b, fo.delta_field(pos, box, 32, True), rtol=1e-11, atol=1e-11)
-    np.testing.assert_allclose(a, c, rtol=1e-12, atol=1e-12)   # atomics: order-dependent only at round-off
+    np.testing.assert_allclose(a, c, rtol=1e-11, atol=1e-11)   # atomics: order-dependent only at round-off (x FFT gain)
     assert abs(b.mean()) < 1e-14

@@ -26,16 +26,8 @@ pos, vel = cosmo.zeldovich_ics(tab, n_side, L, c, a_begin, seed, seed + 1000)
 mass = c.particle_mass(L, n_side ** 3)
 pos, vel = cosmo.run_pp(pos, vel, mass, L, c, a_begin, 1.0, nsteps, dtype=dtype)
 t_run = time.perf_counter() - t0
-with field.FieldPlan(n_side, L) as plan:           # CIC + deconvolution on the GPU, per-mode power on the host
-    plan.cic(pos); plan.affine(plan.mean(), 1.0, 1.0); plan.deconvolve()
-    delta = plan.get()
-dk = np.fft.fftn(delta)
-kv = 2 * np.pi * np.fft.fftfreq(n_side, d=L / n_side)
-kx, ky, kz = np.meshgrid(kv, kv, kv, indexing="ij")
-kmag = np.sqrt(kx ** 2 + ky ** 2 + kz ** 2).ravel()
-pk = (np.abs(dk) ** 2 * L ** 3 / n_side ** 6).ravel()
-sel = kmag > 0
-k_b, p_b = cosmo.rebin_like_concept(kmag[sel], pk[sel], modes if n_side == 64 else modes[: max(2, len(modes) // 2)])
+kmag, pk = cosmo.power_modes(pos, L, n_side, interlace=True)     # CONCEPT's estimator settings: CIC, deconvolved, interlaced
+k_b, p_b = cosmo.rebin_like_concept(kmag, pk, modes if n_side == 64 else modes[: max(2, len(modes) // 2)])
 print(f"# {n_side}^3 particles, {nsteps} steps in ln a, {np.dtype(dtype).name} forces, wall {t_run:.1f} s (CONCEPT: 257257 s)")
 print("#  k_ref      k_here     modes   P_ref        P_here       ratio   P_ref/P_lin  P_here/P_lin")
 for i in range(len(k_b)):
