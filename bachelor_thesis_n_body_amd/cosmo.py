@@ -51,16 +51,28 @@ class Cosmology:
         a = np.linspace(a0, a1, n)
         return float(np.trapezoid(1.0 / (a ** 3 * self.H(a)), a))
 
-    def _D_un(self, a: float, n: int = 4000) -> float:
-        x = np.linspace(1e-8, a, n)
-        return float(self.E(a) * np.trapezoid(1.0 / (x * self.E(x)) ** 3, x))
-
     def growth(self, a: float):
-        """(D(a) with D(1) = 1, f = dlnD/dlna) — the integral solution for flat LCDM."""
-        d1 = self._D_un(1.0)
-        h = 1e-4 * a
-        f = (np.log(self._D_un(a + h)) - np.log(self._D_un(a - h))) / (np.log(a + h) - np.log(a - h))
-        return self._D_un(a) / d1, float(f)
+        """(D(a) with D(1) = 1, f = dlnD/dlna) of sub-horizon matter perturbations, from the linear growth ODE
+            D'' + (2 + dlnH/dlna) D' - (3/2) Omega_m(a) D = 0      (' = d/dlna)
+        started on the growing mode D = a + (2/3) a_eq deep in the radiation era. (The closed integral E(a) int da/(aE)^3 is
+        only a solution without radiation; with Omega_r in E(a) it under-estimates D(0.02) by 3 %, i.e. 6 % in power.)"""
+        from scipy.integrate import solve_ivp
+        Om, Or = self.Om, self.Or
+        OL = 1.0 - Om - Or
+
+        def rhs(x, y):
+            aa = np.exp(x)
+            E2 = Or / aa ** 4 + Om / aa ** 3 + OL
+            dlnH = 0.5 * (-4 * Or / aa ** 4 - 3 * Om / aa ** 3) / E2
+            return [y[1], -(2.0 + dlnH) * y[1] + 1.5 * (Om / aa ** 3 / E2) * y[0]]
+
+        a_eq = Or / Om if Or > 0 else 0.0
+        a0 = 1e-5 if Or > 0 else 1e-4
+        y0 = [a0 + 2.0 / 3.0 * a_eq, a0]
+        sol = solve_ivp(rhs, [np.log(a0), 0.0], y0, rtol=1e-10, atol=1e-14, dense_output=True)
+        d1 = sol.sol(0.0)[0]
+        d, dp = sol.sol(np.log(a))
+        return float(d / d1), float(dp / d)
 
     def particle_mass(self, boxsize: float, n: int, G: float = _params.G_NEWTON) -> float:
         rho_m = self.Om * 3.0 * self.H0 ** 2 / (8.0 * np.pi * G)

@@ -50,3 +50,16 @@ def test_growth_factor_limits():
     assert D == pytest.approx(1.0) and f == pytest.approx(0.31 ** 0.55, rel=0.02)
     D, _ = eo.growth(0.02, 0.31)
     assert D == pytest.approx(0.02 / 0.787, rel=0.02)   # D(a)/a -> 1/g(Om=0.31) with g ~ 0.787
+
+
+def test_product_growth_ode_matches_closed_form_without_radiation():
+    """cosmo.Cosmology.growth solves the growth ODE (valid with radiation); without radiation it must equal the closed
+    integral solution the oracle uses."""
+    from bachelor_thesis_n_body_amd import cosmo
+    c = cosmo.Cosmology.from_h_omegas(0.6736, 0.02237, 0.12, radiation=False)
+    for a in (0.02, 0.1, 0.5, 1.0):
+        D, f = c.growth(a)
+        D0, f0 = eo.growth(a, c.Om)
+        assert D == pytest.approx(D0, rel=1e-6) and f == pytest.approx(f0, rel=1e-5)
+    cr = cosmo.Cosmology.from_h_omegas(0.6736, 0.02237, 0.12, radiation=True)
+    assert cr.growth(0.02)[0] == pytest.approx(1.0094 * c.growth(0.02)[0], rel=2e-3)   # radiation: D ~ a + 2/3 a_eq early on
