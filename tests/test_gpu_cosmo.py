@@ -2,8 +2,8 @@
 spectrum of the thesis' `pp` run (64^3 particles, 500 Mpc periodic box, a = 0.02 -> 1; tests/golden/concept/PP_powerspec_a=1.00
 = PPPMP3M/PP/powerspec/powerspec_a=1.00). The same configuration is run here (Zel'dovich ICs from the table's own linear column,
 comoving KDK, Ewald forces) with a reduced step count and its P(k), binned like CONCEPT's table, must agree with the table
-within realisation scatter. The full 400-step run is tools/run_pp_reference.py (profiles/r01_pp_reference_configuration_64cubed.txt:
-ratio 0.90-1.00 over bins 3-14, 153 s instead of CONCEPT's 257 257 s)."""
+within realisation scatter. The full 400-step run is tools/run_pp_reference.py (profiles/r01_pp_reference_configuration_64cubed_fp32.txt:
+ratio 0.94-1.01 over bins 6-16, 34 s instead of CONCEPT's 257 257 s)."""
 from pathlib import Path
 
 import numpy as np
