@@ -248,7 +248,8 @@ int nb_step(nb_ctx* c, double dt, int64_t nsteps, double eps, double G) {
   // Launch-bound regime (small N, many steps): steps 1..n-1 are identical launch sequences
   // [kick_drift(h, h, dt); a(x)] with constant arguments, so capture one into a hipGraph and replay it.
   static const bool no_graph = getenv("NB_NO_GRAPH") != nullptr;
-  const bool use_graph = !no_graph && c->solver == NB_SOLVER_DIRECT && c->n <= 65536 && nsteps >= 4;
+  // (never on HIP's legacy NULL stream: it cannot be captured)
+  const bool use_graph = !no_graph && c->stream != nullptr && c->solver == NB_SOLVER_DIRECT && c->n <= 65536 && nsteps >= 4;
   for (int64_t k = 0; k < nsteps; ++k) {
     if (use_graph && k >= 1) {
       if (!c->step_graph || c->graph_dt != dt || c->graph_eps != eps || c->graph_G != G) {
