@@ -36,7 +36,9 @@ SIGNATURES = {
     "nb_get_acc": (_int, [_vp, _vp, _vp, _vp]),
     "nb_step": (_int, [_vp, _dbl, _i64, _dbl, _dbl]),
     "nb_energy": (_int, [_vp, _dbl, _dbl, C.POINTER(_dbl), C.POINTER(_dbl)]),
+    "nb_step_energy": (_int, [_vp, _dbl, _i64, _dbl, _dbl, _vp, _vp]),
     "nb_accel_dev": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _int]),
+    "nb_accel_pot_dev": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp, _int]),
     "nb_potential_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _dbl, _vp, _int]),
     "nb_kinetic_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _i64, _vp]),
     "nb_kick_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl]),

@@ -127,6 +127,14 @@ class Engine:
     def step(self, dt: float, nsteps: int = 1, eps: float = 0.0, G: float = 1.0) -> None:
         _lib.check(self._ctx, self._lib.nb_step(self._ctx, dt, int(nsteps), eps, G), "nb_step")
 
+    def step_with_energy(self, dt: float, nsteps: int = 1, eps: float = 0.0, G: float = 1.0) -> Tuple[np.ndarray, np.ndarray]:
+        """`nsteps` KDK steps; returns (kinetic[nsteps], potential[nsteps]) after every step. The potential is a by-product
+        of the force kernel (fused accumulator), not a second O(N^2) pass."""
+        k = np.empty(int(nsteps), np.float64); u = np.empty(int(nsteps), np.float64)
+        _lib.check(self._ctx, self._lib.nb_step_energy(self._ctx, dt, int(nsteps), eps, G, k.ctypes.data_as(C.c_void_p),
+                                                       u.ctypes.data_as(C.c_void_p)), "nb_step_energy")
+        return k, u
+
     def energy(self, eps: float, G: float = 1.0) -> Tuple[float, float]:
         k, u = C.c_double(), C.c_double()
         _lib.check(self._ctx, self._lib.nb_energy(self._ctx, eps, G, C.byref(k), C.byref(u)), "nb_energy")

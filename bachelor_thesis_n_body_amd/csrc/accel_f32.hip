@@ -20,7 +20,9 @@
 //    removes the O(sqrt(N)) growth of the fp32 accumulation error at N = 2^20.
 //  * uniform masses (flag NB_UNIFORM_MASS, the standard equal-mass N-body set-up — every CONCEPT run of the thesis):
 //    the per-source `m*rinv` multiply is dropped (11 instead of 12 full-rate ops) and the common mass is applied once
-//    with G in the fp64 epilogue; padding sources then sit at 1e18 so that rinv^3 underflows to exactly 0.
+//    with G in the fp64 epilogue; padding sources then sit at 1e20 so that r^2 = +inf and rinv = 0 exactly.
+//  * fused potential (POT, requested by passing `phi`): phi_i += m_j rinv costs ONE more packed add per sink pair — the pair
+//    potential of the same positions for 1/12 of a second O(N^2) pass (SURVEY.md §8a row ⊕3: "fuse with ⊕1").
 //  * small N: the source range is split over gridDim.y so the grid still fills 256 CUs; partial sums go
 //    to an fp64 slab [split][3][n_snk] and a second tiny kernel reduces them in a fixed order
 //    (bit-reproducible — no float atomics).
@@ -33,7 +35,7 @@ namespace {
 constexpr int BLOCK = 256;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int KS, int U, int TILE, bool GUARD, bool UNIFORM>
+template <int KS, int U, int TILE, bool GUARD, bool UNIFORM, bool POT>
 __global__ void __launch_bounds__(BLOCK)
 accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, const float* __restrict__ zi,
                  int n_snk,
@@ -41,7 +43,7 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
                  const float* __restrict__ ms, int n_src, int src_per_split,
                  float eps2, float G,
                  float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az,
-                 double* __restrict__ part, int accumulate) {
+                 double* __restrict__ part, int accumulate, double* __restrict__ phi) {
   static_assert(TILE % BLOCK == 0, "tile must be a multiple of the block size");
   constexpr int LPT = TILE / BLOCK;  // staged sources per thread
   __shared__ float4 tile[2][TILE];
@@ -61,9 +63,9 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
     ib = ib < n_snk ? ib : n_snk - 1;
     px[p] = v2f{xi[ia], xi[ib]}; py[p] = v2f{yi[ia], yi[ib]}; pz[p] = v2f{zi[ia], zi[ib]};
   }
-  double tx[KS], ty[KS], tz[KS];
+  double tx[KS], ty[KS], tz[KS], tp[KS];   // tp: potential sum_j m_j / sqrt(r^2+eps^2) (POT only; dead code otherwise)
 #pragma unroll
-  for (int k = 0; k < KS; ++k) { tx[k] = 0.0; ty[k] = 0.0; tz[k] = 0.0; }
+  for (int k = 0; k < KS; ++k) { tx[k] = 0.0; ty[k] = 0.0; tz[k] = 0.0; tp[k] = 0.0; }
   // eps^2 lives in a VGPR pair: an SGPR operand halves the VALU issue rate on gfx950 (tools/ubench_valu)
   v2f e2;
   asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2" : "=v"(e2.x), "=v"(e2.y) : "s"(eps2));
@@ -80,8 +82,9 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
       bool ok = j < jend;
       int jc = ok ? j : jend - 1;
       // padding sources carry zero mass: they add exactly 0 (their r^2 + eps^2 > 0, or GUARD zeroes them).
-      // In UNIFORM mode the mass is not read per source, so padding sits at 1e18 instead: rinv^3 underflows to 0.
-      const float far = 1e18f;
+      // In UNIFORM mode the mass is not read per source, so padding sits at 1e20 instead: r^2 overflows to +inf,
+      // v_rsq_f32(+inf) = +0, and both the force and the potential term are exactly 0.
+      const float far = 1e20f;
       stage[l] = UNIFORM ? make_float4(ok ? xs[jc] : far, ok ? ys[jc] : far, ok ? zs[jc] : far, 0.0f)
                          : make_float4(xs[jc], ys[jc], zs[jc], ok ? ms[jc] : 0.0f);
     }
@@ -102,9 +105,9 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
     const int buf = t & 1;
     if (t + 1 < ntiles) fetch(t + 1);
 
-    v2f fx[KP], fy[KP], fz[KP];
+    v2f fx[KP], fy[KP], fz[KP], fp[KP];
 #pragma unroll
-    for (int p = 0; p < KP; ++p) { fx[p] = v2f{0.f, 0.f}; fy[p] = v2f{0.f, 0.f}; fz[p] = v2f{0.f, 0.f}; }
+    for (int p = 0; p < KP; ++p) { fx[p] = v2f{0.f, 0.f}; fy[p] = v2f{0.f, 0.f}; fz[p] = v2f{0.f, 0.f}; fp[p] = v2f{0.f, 0.f}; }
 
     // U sources x KP sink pairs = U*KP independent dependency chains per group, written breadth-first (all
     // chains do stage 1, then all do stage 2, ...) so that a wave never issues an instruction that needs the
@@ -143,8 +146,14 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
         for (int p = 0; p < KP; ++p) {
           const v2f rinv2 = rinv[u][p] * rinv[u][p];
           v2f f;
-          if (UNIFORM) f = rinv2 * rinv[u][p];                                  // common mass applied once, at the end
-          else f = (v2f{s[u].w, s[u].w} * rinv[u][p]) * rinv2;
+          if (UNIFORM) {                                                        // common mass applied once, at the end
+            f = rinv2 * rinv[u][p];
+            if (POT) fp[p] = fp[p] + rinv[u][p];
+          } else {
+            const v2f mr = v2f{s[u].w, s[u].w} * rinv[u][p];
+            f = mr * rinv2;
+            if (POT) fp[p] = fp[p] + mr;
+          }
           fx[p] = __builtin_elementwise_fma(f, dx[u][p], fx[p]);
           fy[p] = __builtin_elementwise_fma(f, dy[u][p], fy[p]);
           fz[p] = __builtin_elementwise_fma(f, dz[u][p], fz[p]);
@@ -154,6 +163,7 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
     for (int p = 0; p < KP; ++p) {
       tx[2 * p] += (double)fx[p].x; ty[2 * p] += (double)fy[p].x; tz[2 * p] += (double)fz[p].x;
       tx[2 * p + 1] += (double)fx[p].y; ty[2 * p + 1] += (double)fy[p].y; tz[2 * p + 1] += (double)fz[p].y;
+      if (POT) { tp[2 * p] += (double)fp[p].x; tp[2 * p + 1] += (double)fp[p].y; }
     }
 
     if (t + 1 < ntiles) commit(buf ^ 1);
@@ -169,14 +179,22 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
         float ox = (float)(g * tx[k]), oy = (float)(g * ty[k]), oz = (float)(g * tz[k]);
         if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
         ax[i] = ox; ay[i] = oy; az[i] = oz;
+        if (POT) {   // potential per unit G: sum_j m_j / sqrt(r^2+eps^2), self term included (removed by the caller)
+          const double ph = (UNIFORM ? (double)ms[0] : 1.0) * tp[k];
+          phi[i] = accumulate ? phi[i] + ph : ph;
+        }
       }
     }
   } else {
-    double* p = part + (size_t)blockIdx.y * 3 * (size_t)n_snk;
+    constexpr int NC = POT ? 4 : 3;
+    double* p = part + (size_t)blockIdx.y * NC * (size_t)n_snk;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       const int i = i0 + k * BLOCK;
-      if (i < n_snk) { p[i] = tx[k]; p[(size_t)n_snk + i] = ty[k]; p[2 * (size_t)n_snk + i] = tz[k]; }
+      if (i < n_snk) {
+        p[i] = tx[k]; p[(size_t)n_snk + i] = ty[k]; p[2 * (size_t)n_snk + i] = tz[k];
+        if (POT) p[3 * (size_t)n_snk + i] = tp[k];
+      }
     }
   }
 }
@@ -184,14 +202,18 @@ accel_f32_kernel(const float* __restrict__ xi, const float* __restrict__ yi, con
 // out[c][i] (+)= G * sum_s part[s][c][i], fixed summation order
 __global__ void __launch_bounds__(256)
 accel_reduce_f32_kernel(const double* __restrict__ part, int nsplit, int n_snk, float G, const float* __restrict__ m0,
-                        float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, int accumulate) {
+                        float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, int accumulate,
+                        double* __restrict__ phi) {
+  const int nc = phi ? 4 : 3;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_snk) return;
-  double sx = 0.0, sy = 0.0, sz = 0.0;
+  double sx = 0.0, sy = 0.0, sz = 0.0, sp = 0.0;
   for (int s = 0; s < nsplit; ++s) {
-    const double* p = part + (size_t)s * 3 * (size_t)n_snk;
+    const double* p = part + (size_t)s * nc * (size_t)n_snk;
     sx += p[i]; sy += p[(size_t)n_snk + i]; sz += p[2 * (size_t)n_snk + i];
+    if (phi) sp += p[3 * (size_t)n_snk + i];
   }
+  if (phi) { const double ph = (m0 ? (double)m0[0] : 1.0) * sp; phi[i] = accumulate ? phi[i] + ph : ph; }
   const double g = m0 ? (double)G * (double)m0[0] : (double)G;   // uniform-mass mode: common mass applied here
   float ox = (float)(g * sx), oy = (float)(g * sy), oz = (float)(g * sz);
   if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
@@ -206,11 +228,20 @@ int env_int(const char* name, int dflt) {
 template <int KS, int U, int TILE>
 void launch_variant(bool guard, bool uniform, dim3 grid, hipStream_t st, const float* xi, const float* yi, const float* zi,
                     int n_snk, const float* xs, const float* ys, const float* zs, const float* ms, int n_src,
-                    int sps, float eps2, float G, float* ax, float* ay, float* az, double* part, int accumulate) {
-#define NB_LAUNCH(GD, UF) accel_f32_kernel<KS, U, TILE, GD, UF><<<grid, BLOCK, 0, st>>>( \
-    xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps, eps2, G, ax, ay, az, part, accumulate)
-  if (guard) { if (uniform) NB_LAUNCH(true, true); else NB_LAUNCH(true, false); }
-  else       { if (uniform) NB_LAUNCH(false, true); else NB_LAUNCH(false, false); }
+                    int sps, float eps2, float G, float* ax, float* ay, float* az, double* part, int accumulate, double* phi) {
+#define NB_LAUNCH(GD, UF, PT) accel_f32_kernel<KS, U, TILE, GD, UF, PT><<<grid, BLOCK, 0, st>>>( \
+    xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps, eps2, G, ax, ay, az, part, accumulate, phi)
+  const int v = (guard ? 4 : 0) | (uniform ? 2 : 0) | (phi ? 1 : 0);
+  switch (v) {
+    case 0: NB_LAUNCH(false, false, false); break;
+    case 1: NB_LAUNCH(false, false, true); break;
+    case 2: NB_LAUNCH(false, true, false); break;
+    case 3: NB_LAUNCH(false, true, true); break;
+    case 4: NB_LAUNCH(true, false, false); break;
+    case 5: NB_LAUNCH(true, false, true); break;
+    case 6: NB_LAUNCH(true, true, false); break;
+    default: NB_LAUNCH(true, true, true); break;
+  }
 #undef NB_LAUNCH
 }
 
@@ -218,7 +249,7 @@ void launch_variant(bool guard, bool uniform, dim3 grid, hipStream_t st, const f
 
 int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, int64_t n_snk,
                         const float* xs, const float* ys, const float* zs, const float* ms, int64_t n_src,
-                        float eps2, float G, float* ax, float* ay, float* az, int flags) {
+                        float eps2, float G, float* ax, float* ay, float* az, int flags, double* phi) {
   if (n_snk <= 0) return NB_OK;
   const int accumulate = flags & NB_ACCUMULATE;
   const bool uniform = (flags & NB_UNIFORM_MASS) && n_src > 0;
@@ -247,13 +278,13 @@ int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float
 
   double* part = nullptr;
   if (nsplit > 1) {
-    int rc = nb_ensure_work(c, (size_t)nsplit * 3 * (size_t)n_snk * sizeof(double));
+    int rc = nb_ensure_work(c, (size_t)nsplit * (phi ? 4 : 3) * (size_t)n_snk * sizeof(double));
     if (rc) return rc;
     part = reinterpret_cast<double*>(c->work);
   }
   const bool guard = !(eps2 >= 1e-20f);
   dim3 grid(nblk, nsplit);
-#define NB_GO(K, UU) launch_variant<K, UU, TILE>(guard, uniform, grid, c->stream, xi, yi, zi, (int)n_snk, xs, ys, zs, ms, (int)n_src, sps, eps2, G, ax, ay, az, part, accumulate)
+#define NB_GO(K, UU) launch_variant<K, UU, TILE>(guard, uniform, grid, c->stream, xi, yi, zi, (int)n_snk, xs, ys, zs, ms, (int)n_src, sps, eps2, G, ax, ay, az, part, accumulate, phi)
   switch (ks) {
     case 2: NB_GO(2, 2); break;
     case 4: NB_GO(4, 2); break;
@@ -262,7 +293,7 @@ int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float
 #undef NB_GO
   NB_HIP(c, hipGetLastError());
   if (nsplit > 1) {
-    accel_reduce_f32_kernel<<<(int)((n_snk + 255) / 256), 256, 0, c->stream>>>(part, nsplit, (int)n_snk, G, uniform ? ms : nullptr, ax, ay, az, accumulate);
+    accel_reduce_f32_kernel<<<(int)((n_snk + 255) / 256), 256, 0, c->stream>>>(part, nsplit, (int)n_snk, G, uniform ? ms : nullptr, ax, ay, az, accumulate, phi);
     NB_HIP(c, hipGetLastError());
   }
   return NB_OK;

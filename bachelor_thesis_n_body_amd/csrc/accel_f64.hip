@@ -20,8 +20,8 @@ struct d4 { double x, y, z, w; };
 // m / (r2)^{3/2} from a hardware rsqrt seed y ~ r2^{-1/2}:  with h = 1 - r2*y^2,
 //   r2^{-3/2} = y^3 (1-h)^{-3/2} = y^3 (1 + 3/2 h + 15/8 h^2 + O(h^3)),   |h| <~ 2^-23  ->  error ~ 3 h^3 < 1e-20
 // 7 fp64 VALU ops after the seed (one fewer than refining y first and cubing afterwards).
-template <int RSQ_MODE>
-__device__ inline double m_over_r3(double m, double r2) {
+template <int RSQ_MODE, bool POT>
+__device__ inline double m_over_r3(double m, double r2, double& m_over_r) {
   double y;
   if (RSQ_MODE == 1) y = (double)__builtin_amdgcn_rsqf((float)r2);   // r2 must fit the fp32 range
   else y = __builtin_amdgcn_rsq(r2);                                   // v_rsq_f64
@@ -29,10 +29,11 @@ __device__ inline double m_over_r3(double m, double r2) {
   const double h = fma(-r2, y2, 1.0);
   const double q = fma(fma(1.875, h, 1.5), h, 1.0);
   const double my = m * y;
+  if (POT) m_over_r = my * fma(fma(0.375, h, 0.5), h, 1.0);     // m r2^{-1/2} = m y (1 + h/2 + 3h^2/8)
   return (my * y2) * q;
 }
 
-template <int KS, int TILE, bool GUARD, int RSQ_MODE>
+template <int KS, int TILE, bool GUARD, int RSQ_MODE, bool POT>
 __global__ void __launch_bounds__(BLOCK)
 accel_f64_kernel(const double* __restrict__ xi, const double* __restrict__ yi, const double* __restrict__ zi,
                  int n_snk,
@@ -40,7 +41,7 @@ accel_f64_kernel(const double* __restrict__ xi, const double* __restrict__ yi, c
                  const double* __restrict__ ms, int n_src, int src_per_split,
                  double eps2, double G,
                  double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az,
-                 double* __restrict__ part, int accumulate) {
+                 double* __restrict__ part, int accumulate, double* __restrict__ phi) {
   static_assert(TILE % BLOCK == 0, "tile must be a multiple of the block size");
   constexpr int LPT = TILE / BLOCK;
   __shared__ d4 tile[2][TILE];
@@ -48,13 +49,13 @@ accel_f64_kernel(const double* __restrict__ xi, const double* __restrict__ yi, c
   const int tid = threadIdx.x;
   const int i0 = blockIdx.x * (BLOCK * KS) + tid;
 
-  double px[KS], py[KS], pz[KS], fx[KS], fy[KS], fz[KS];
+  double px[KS], py[KS], pz[KS], fx[KS], fy[KS], fz[KS], fp[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
     int i = i0 + k * BLOCK;
     i = i < n_snk ? i : n_snk - 1;
     px[k] = xi[i]; py[k] = yi[i]; pz[k] = zi[i];
-    fx[k] = 0.0; fy[k] = 0.0; fz[k] = 0.0;
+    fx[k] = 0.0; fy[k] = 0.0; fz[k] = 0.0; fp[k] = 0.0;
   }
   double e2 = eps2;
   asm volatile("" : "+v"(e2));  // keep eps^2 in VGPRs (SGPR operands halve the VALU issue rate)
@@ -95,8 +96,10 @@ accel_f64_kernel(const double* __restrict__ xi, const double* __restrict__ yi, c
         const double dy = s.y - py[k];
         const double dz = s.z - pz[k];
         const double r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, e2)));
-        double f = m_over_r3<RSQ_MODE>(s.w, r2);
-        if (GUARD) f = r2 > e2 ? f : 0.0;   // coincident pair (dx=dy=dz=0) at eps = 0: contributes nothing
+        double mr = 0.0;
+        double f = m_over_r3<RSQ_MODE, POT>(s.w, r2, mr);
+        if (GUARD) { const bool far = r2 > e2; f = far ? f : 0.0; mr = far ? mr : 0.0; }   // coincident pair at eps = 0: nothing
+        if (POT) fp[k] += mr;
         fx[k] = fma(f, dx, fx[k]);
         fy[k] = fma(f, dy, fy[k]);
         fz[k] = fma(f, dz, fz[k]);
@@ -114,28 +117,37 @@ accel_f64_kernel(const double* __restrict__ xi, const double* __restrict__ yi, c
         double ox = G * fx[k], oy = G * fy[k], oz = G * fz[k];
         if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
         ax[i] = ox; ay[i] = oy; az[i] = oz;
+        if (POT) phi[i] = accumulate ? phi[i] + fp[k] : fp[k];
       }
     }
   } else {
-    double* p = part + (size_t)blockIdx.y * 3 * (size_t)n_snk;
+    constexpr int NC = POT ? 4 : 3;
+    double* p = part + (size_t)blockIdx.y * NC * (size_t)n_snk;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       const int i = i0 + k * BLOCK;
-      if (i < n_snk) { p[i] = fx[k]; p[(size_t)n_snk + i] = fy[k]; p[2 * (size_t)n_snk + i] = fz[k]; }
+      if (i < n_snk) {
+        p[i] = fx[k]; p[(size_t)n_snk + i] = fy[k]; p[2 * (size_t)n_snk + i] = fz[k];
+        if (POT) p[3 * (size_t)n_snk + i] = fp[k];
+      }
     }
   }
 }
 
 __global__ void __launch_bounds__(256)
 accel_reduce_f64_kernel(const double* __restrict__ part, int nsplit, int n_snk, double G,
-                        double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az, int accumulate) {
+                        double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az, int accumulate,
+                        double* __restrict__ phi) {
+  const int nc = phi ? 4 : 3;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_snk) return;
-  double sx = 0.0, sy = 0.0, sz = 0.0;
+  double sx = 0.0, sy = 0.0, sz = 0.0, sp = 0.0;
   for (int s = 0; s < nsplit; ++s) {
-    const double* p = part + (size_t)s * 3 * (size_t)n_snk;
+    const double* p = part + (size_t)s * nc * (size_t)n_snk;
     sx += p[i]; sy += p[(size_t)n_snk + i]; sz += p[2 * (size_t)n_snk + i];
+    if (phi) sp += p[3 * (size_t)n_snk + i];
   }
+  if (phi) phi[i] = accumulate ? phi[i] + sp : sp;
   double ox = G * sx, oy = G * sy, oz = G * sz;
   if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
   ax[i] = ox; ay[i] = oy; az[i] = oz;
@@ -149,20 +161,19 @@ int env_int(const char* name, int dflt) {
 template <int KS, int TILE, int RSQ_MODE>
 void launch_variant(bool guard, dim3 grid, hipStream_t st, const double* xi, const double* yi, const double* zi,
                     int n_snk, const double* xs, const double* ys, const double* zs, const double* ms, int n_src,
-                    int sps, double eps2, double G, double* ax, double* ay, double* az, double* part, int accumulate) {
-  if (guard)
-    accel_f64_kernel<KS, TILE, true, RSQ_MODE><<<grid, BLOCK, 0, st>>>(xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps,
-                                                                      eps2, G, ax, ay, az, part, accumulate);
-  else
-    accel_f64_kernel<KS, TILE, false, RSQ_MODE><<<grid, BLOCK, 0, st>>>(xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps,
-                                                                       eps2, G, ax, ay, az, part, accumulate);
+                    int sps, double eps2, double G, double* ax, double* ay, double* az, double* part, int accumulate, double* phi) {
+#define NB_LAUNCH(GD, PT) accel_f64_kernel<KS, TILE, GD, RSQ_MODE, PT><<<grid, BLOCK, 0, st>>>( \
+    xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, sps, eps2, G, ax, ay, az, part, accumulate, phi)
+  if (guard) { if (phi) NB_LAUNCH(true, true); else NB_LAUNCH(true, false); }
+  else       { if (phi) NB_LAUNCH(false, true); else NB_LAUNCH(false, false); }
+#undef NB_LAUNCH
 }
 
 }  // namespace
 
 int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const double* zi, int64_t n_snk,
                         const double* xs, const double* ys, const double* zs, const double* ms, int64_t n_src,
-                        double eps2, double G, double* ax, double* ay, double* az, int flags) {
+                        double eps2, double G, double* ax, double* ay, double* az, int flags, double* phi) {
   if (n_snk <= 0) return NB_OK;
   const int accumulate = flags & NB_ACCUMULATE;   // NB_UNIFORM_MASS is a hint the fp64 kernel does not need
   if (n_snk >= (1ll << 31) || n_src >= (1ll << 31)) return nb_fail(c, NB_ERR_ARG, "n must be < 2^31");
@@ -185,13 +196,13 @@ int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const dou
 
   double* part = nullptr;
   if (nsplit > 1) {
-    int rc = nb_ensure_work(c, (size_t)nsplit * 3 * (size_t)n_snk * sizeof(double));
+    int rc = nb_ensure_work(c, (size_t)nsplit * (phi ? 4 : 3) * (size_t)n_snk * sizeof(double));
     if (rc) return rc;
     part = reinterpret_cast<double*>(c->work);
   }
   const bool guard = !(eps2 > 0.0);
   dim3 grid(nblk, nsplit);
-#define NB_GO(K, M) launch_variant<K, TILE, M>(guard, grid, c->stream, xi, yi, zi, (int)n_snk, xs, ys, zs, ms, (int)n_src, sps, eps2, G, ax, ay, az, part, accumulate)
+#define NB_GO(K, M) launch_variant<K, TILE, M>(guard, grid, c->stream, xi, yi, zi, (int)n_snk, xs, ys, zs, ms, (int)n_src, sps, eps2, G, ax, ay, az, part, accumulate, phi)
   if (rsq_mode == 1) {
     if (ks == 1) NB_GO(1, 1); else if (ks == 4) NB_GO(4, 1); else NB_GO(2, 1);
   } else {
@@ -200,7 +211,7 @@ int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const dou
 #undef NB_GO
   NB_HIP(c, hipGetLastError());
   if (nsplit > 1) {
-    accel_reduce_f64_kernel<<<(int)((n_snk + 255) / 256), 256, 0, c->stream>>>(part, nsplit, (int)n_snk, G, ax, ay, az, accumulate);
+    accel_reduce_f64_kernel<<<(int)((n_snk + 255) / 256), 256, 0, c->stream>>>(part, nsplit, (int)n_snk, G, ax, ay, az, accumulate, phi);
     NB_HIP(c, hipGetLastError());
   }
   return NB_OK;

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 static thread_local std::string g_create_err;
 
@@ -97,6 +98,8 @@ int nb_destroy(nb_ctx* c) {
   if (c->state) (void)hipFree(c->state);
   if (c->work) (void)hipFree(c->work);
   if (c->scal) (void)hipFree(c->scal);
+  if (c->phi) (void)hipFree(c->phi);
+  if (c->elog) (void)hipFree(c->elog);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return NB_OK;
@@ -174,8 +177,9 @@ int nb_get_state(nb_ctx* c, void* x, void* y, void* z, void* vx, void* vy, void*
 }
 
 // a(x) of the context's own particles into the state's ax/ay/az fields
-static int refresh_acc(nb_ctx* c, double eps, double G) {
+static int refresh_acc(nb_ctx* c, double eps, double G, double* phi = nullptr) {
   int rc;
+  if (phi && c->solver != NB_SOLVER_DIRECT) return nb_fail(c, NB_ERR_ARG, "the fused potential needs the direct solver");
   if (c->solver == NB_SOLVER_EWALD) {
     const size_t b = (size_t)c->n * esize(c->dtype);
     char* s = reinterpret_cast<char*>(c->state);
@@ -192,12 +196,12 @@ static int refresh_acc(nb_ctx* c, double eps, double G) {
     const size_t n = (size_t)c->n;
     rc = nb_launch_accel_f32(c, s, s + n, s + 2 * n, c->n, s, s + n, s + 2 * n, s + 3 * n, c->n,
                              (float)(eps * eps), (float)G, s + 7 * n, s + 8 * n, s + 9 * n,
-                             c->uniform_mass ? NB_UNIFORM_MASS : 0);
+                             c->uniform_mass ? NB_UNIFORM_MASS : 0, phi);
   } else {
     double* s = reinterpret_cast<double*>(c->state);
     const size_t n = (size_t)c->n;
     rc = nb_launch_accel_f64(c, s, s + n, s + 2 * n, c->n, s, s + n, s + 2 * n, s + 3 * n, c->n, eps * eps, G,
-                             s + 7 * n, s + 8 * n, s + 9 * n, 0);
+                             s + 7 * n, s + 8 * n, s + 9 * n, 0, phi);
   }
   if (rc) return rc;
   c->acc_valid = true; c->acc_eps = eps; c->acc_G = G;
@@ -325,6 +329,47 @@ int nb_energy(nb_ctx* c, double eps, double G, double* kinetic, double* potentia
   return NB_OK;
 }
 
+// KDK steps with the energies of every step: the potential comes out of the force kernel itself (one extra
+// accumulator per sink, SURVEY.md §8a row ⊕3) instead of a second O(N^2) pass per diagnostic.
+int nb_step_energy(nb_ctx* c, double dt, int64_t nsteps, double eps, double G, double* kinetic, double* potential) {
+  if (!c) return NB_ERR_ARG;
+  if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_step_energy: call nb_set_state first");
+  if (nsteps < 0) return nb_fail(c, NB_ERR_ARG, "nb_step_energy: nsteps must be >= 0");
+  if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_step_energy: eps must be >= 0");
+  if (c->solver != NB_SOLVER_DIRECT) return nb_fail(c, NB_ERR_ARG, "nb_step_energy: direct solver only");
+  if (nsteps == 0) return NB_OK;
+  int rc = use_device(c); if (rc) return rc;
+  if (!c->phi) NB_HIP(c, hipMalloc(&c->phi, (size_t)c->n * sizeof(double)));
+  if (c->elog_cap < nsteps) {
+    NB_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->elog) { (void)hipFree(c->elog); c->elog = nullptr; c->elog_cap = 0; }
+    NB_HIP(c, hipMalloc(&c->elog, (size_t)nsteps * 2 * sizeof(double)));
+    c->elog_cap = nsteps;
+  }
+  if (!c->acc_valid || c->acc_eps != eps || c->acc_G != G) { rc = refresh_acc(c, eps, G); if (rc) return rc; }
+  const size_t b = (size_t)c->n * esize(c->dtype);
+  char* s = reinterpret_cast<char*>(c->state);
+  void *x = s, *y = s + b, *z = s + 2 * b, *m = s + 3 * b, *vx = s + 4 * b, *vy = s + 5 * b, *vz = s + 6 * b;
+  void *ax = s + 7 * b, *ay = s + 8 * b, *az = s + 9 * b;
+  const double h = 0.5 * dt;
+  for (int64_t k = 0; k < nsteps; ++k) {
+    rc = nb_launch_kick_drift(c, c->dtype, x, y, z, vx, vy, vz, ax, ay, az, c->n, 0.0, h, dt); if (rc) return rc;
+    rc = refresh_acc(c, eps, G, c->phi); if (rc) return rc;
+    rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, h); if (rc) return rc;   // synchronised velocities
+    rc = nb_launch_kinetic(c, c->dtype, vx, vy, vz, m, c->n, c->elog + 2 * k); if (rc) return rc;
+    rc = nb_launch_pot_energy(c, c->dtype, c->phi, m, c->n, eps * eps, c->dtype == NB_F32 && c->uniform_mass,
+                              c->elog + 2 * k + 1); if (rc) return rc;
+  }
+  std::vector<double> host((size_t)nsteps * 2);
+  NB_HIP(c, hipMemcpyAsync(host.data(), c->elog, host.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  for (int64_t k = 0; k < nsteps; ++k) {
+    if (kinetic) kinetic[k] = host[2 * k];
+    if (potential) potential[k] = -0.5 * G * host[2 * k + 1];
+  }
+  return NB_OK;
+}
+
 /* ---------------- device-pointer surface ---------------- */
 
 int nb_accel_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const void* zi, int64_t n_snk,
@@ -345,6 +390,26 @@ int nb_accel_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const voi
                                (const double*)ys, (const double*)zs, (const double*)ms, n_src, eps * eps, G,
                                (double*)ax, (double*)ay, (double*)az, flags);
   return nb_fail(c, NB_ERR_ARG, "nb_accel_dev: unknown dtype");
+}
+
+int nb_accel_pot_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const void* zi, int64_t n_snk,
+                     const void* xs, const void* ys, const void* zs, const void* ms, int64_t n_src,
+                     double eps, double G, void* ax, void* ay, void* az, double* phi, int flags) {
+  if (!c) return NB_ERR_ARG;
+  if (n_snk < 0 || n_src < 0) return nb_fail(c, NB_ERR_ARG, "nb_accel_pot_dev: negative count");
+  if (n_snk > 0 && (!xi || !yi || !zi || !ax || !ay || !az || !phi)) return nb_fail(c, NB_ERR_ARG, "nb_accel_pot_dev: NULL sink array");
+  if (n_src > 0 && (!xs || !ys || !zs || !ms)) return nb_fail(c, NB_ERR_ARG, "nb_accel_pot_dev: NULL source array");
+  if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_accel_pot_dev: eps must be >= 0");
+  int rc = use_device(c); if (rc) return rc;
+  if (dtype == NB_F32)
+    return nb_launch_accel_f32(c, (const float*)xi, (const float*)yi, (const float*)zi, n_snk, (const float*)xs,
+                               (const float*)ys, (const float*)zs, (const float*)ms, n_src, (float)(eps * eps),
+                               (float)G, (float*)ax, (float*)ay, (float*)az, flags, phi);
+  if (dtype == NB_F64)
+    return nb_launch_accel_f64(c, (const double*)xi, (const double*)yi, (const double*)zi, n_snk, (const double*)xs,
+                               (const double*)ys, (const double*)zs, (const double*)ms, n_src, eps * eps, G,
+                               (double*)ax, (double*)ay, (double*)az, flags, phi);
+  return nb_fail(c, NB_ERR_ARG, "nb_accel_pot_dev: unknown dtype");
 }
 
 int nb_potential_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const void* zi, const void* mi,

@@ -68,6 +68,38 @@ kinetic_partial_kernel(const T* __restrict__ vx, const T* __restrict__ vy, const
   if (threadIdx.x == 0) part[blockIdx.x] = 0.5 * red[0];
 }
 
+// per-block fp64 partial of sum_i m_i (phi_i - self_i). phi_i comes from the fused force+potential kernels
+// (accel_f32.hip / accel_f64.hip), which do not skip j == i: the self term is what THEY added for r = 0 —
+//   fp32, per-source mass:  (float)(m_i * v_rsq_f32(eps^2));   fp32, uniform mass: m_0 * (double)v_rsq_f32(eps^2);
+//   fp64: m_i / sqrt(eps^2);   eps = 0: nothing (the GUARD variants drop coincident pairs).
+template <typename T>
+__global__ void __launch_bounds__(256)
+pot_energy_partial_kernel(const double* __restrict__ phi, const T* __restrict__ m, int64_t n, double eps2, int uniform,
+                          double* __restrict__ part) {
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const T mi = m[i];
+    double self = 0.0;
+    if (eps2 > 0.0) {
+      if (sizeof(T) == 4) {
+        const float ri = __builtin_amdgcn_rsqf((float)eps2);
+        self = uniform ? (double)mi * (double)ri : (double)((float)mi * ri);
+      } else {
+        self = (double)mi / sqrt(eps2);
+      }
+    }
+    s += (double)mi * (phi[i] - self);
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
 // out[0] = (accumulate ? out[0] : 0) + scale * sum_b part[b]     (single block, fixed order)
 __global__ void __launch_bounds__(256)
 final_sum_kernel(const double* __restrict__ part, int nparts, double scale, double* __restrict__ out,
@@ -153,4 +185,18 @@ int nb_launch_kinetic(nb_ctx* c, int dtype, const void* vx, const void* vy, cons
                                                                 (const double*)vz, (const double*)m, n, part);
   NB_HIP(c, hipGetLastError());
   return nb_launch_final_sum(c, part, grid, 1.0, k_out, 0);
+}
+
+int nb_launch_pot_energy(nb_ctx* c, int dtype, const double* phi, const void* m, int64_t n, double eps2, int uniform,
+                         double* w_out) {
+  const int grid = stream_grid(n);
+  int rc = nb_ensure_work(c, (size_t)grid * sizeof(double));
+  if (rc) return rc;
+  double* part = reinterpret_cast<double*>(c->work);
+  if (dtype == NB_F32)
+    pot_energy_partial_kernel<float><<<grid, 256, 0, c->stream>>>(phi, (const float*)m, n, (double)(float)eps2, uniform, part);
+  else
+    pot_energy_partial_kernel<double><<<grid, 256, 0, c->stream>>>(phi, (const double*)m, n, eps2, uniform, part);
+  NB_HIP(c, hipGetLastError());
+  return nb_launch_final_sum(c, part, grid, 1.0, w_out, 0);
 }

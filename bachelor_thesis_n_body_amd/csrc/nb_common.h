@@ -24,6 +24,9 @@ struct nb_ctx {
   void* work = nullptr;
   size_t work_bytes = 0;
   double* scal = nullptr;     // device scalars (energy reductions)
+  double* phi = nullptr;      // per-particle potential sum_j m_j/sqrt(r^2+eps^2) from the fused force+potential kernel (lazy)
+  double* elog = nullptr;     // (K, W) pairs of nb_step_energy, one per step (lazy, elog_cap pairs)
+  int64_t elog_cap = 0;
   // one KDK step [kick_drift(h,h,dt); a(x)] captured as a hipGraph and replayed for launch-bound (small-N) runs
   hipGraphExec_t step_graph = nullptr;
   double graph_dt = 0.0, graph_eps = -1.0, graph_G = 0.0;
@@ -51,10 +54,10 @@ int nb_ensure_work(nb_ctx* c, size_t bytes);
 // launchers (defined in the kernel translation units); all asynchronous on c->stream
 int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, int64_t n_snk,
                         const float* xs, const float* ys, const float* zs, const float* ms, int64_t n_src,
-                        float eps2, float G, float* ax, float* ay, float* az, int flags);
+                        float eps2, float G, float* ax, float* ay, float* az, int flags, double* phi = nullptr);
 int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const double* zi, int64_t n_snk,
                         const double* xs, const double* ys, const double* zs, const double* ms, int64_t n_src,
-                        double eps2, double G, double* ax, double* ay, double* az, int flags);
+                        double eps2, double G, double* ax, double* ay, double* az, int flags, double* phi = nullptr);
 // Barnes-Hut acceleration of n particles on themselves (fp32); falls back to the direct sum for n < 128 or theta <= 0
 int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
                              float eps2, float G, float theta, float* ax, float* ay, float* az);
@@ -75,6 +78,9 @@ int nb_launch_potential_f64(nb_ctx* c, const double* xi, const double* yi, const
                             int accumulate);
 // out[0] = (accumulate ? out[0] : 0) + scale * sum(part[0..nparts)), one block, fixed order
 int nb_launch_final_sum(nb_ctx* c, const double* part, int nparts, double scale, double* out, int accumulate);
+// w_out[0] = sum_i m_i (phi_i - self_i), self_i = the i==j term the fused kernel included (see integrate.hip)
+int nb_launch_pot_energy(nb_ctx* c, int dtype, const double* phi, const void* m, int64_t n, double eps2, int uniform,
+                         double* w_out);
 int nb_launch_kinetic(nb_ctx* c, int dtype, const void* vx, const void* vy, const void* vz, const void* m,
                       int64_t n, double* k_out);
 int nb_launch_kick(nb_ctx* c, int dtype, void* vx, void* vy, void* vz, const void* ax, const void* ay,

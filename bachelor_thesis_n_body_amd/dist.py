@@ -90,6 +90,18 @@ class HipKernels:
                                     ax, ay, az, (_lib.NB_ACCUMULATE if accumulate else 0) | (_lib.NB_UNIFORM_MASS if uniform_mass else 0))
         _lib.check(self._ctx, rc, "nb_accel_dev")
 
+    def accel_pot(self, snk, n_snk, src, n_src, eps, G, acc, phi, accumulate, uniform_mass=False):
+        """accel() that also fills phi (float64[n_snk]): sum_j m_j / sqrt(r^2 + eps^2), self term included, no G."""
+        self._bind()
+        assert phi.dtype == self._torch.float64 and phi.is_contiguous() and phi.numel() >= n_snk
+        xi, yi, zi = self._rows(snk, 3)
+        xs, ys, zs, ms = self._rows(src, 4)
+        ax, ay, az = self._rows(acc, 3)
+        rc = self._lib.nb_accel_pot_dev(self._ctx, self._code(snk), xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, eps, G,
+                                        ax, ay, az, C.c_void_p(phi.data_ptr()),
+                                        (_lib.NB_ACCUMULATE if accumulate else 0) | (_lib.NB_UNIFORM_MASS if uniform_mass else 0))
+        _lib.check(self._ctx, rc, "nb_accel_pot_dev")
+
     def potential(self, snk, n_snk, snk_g0, src, n_src, src_g0, eps, out, accumulate):
         self._bind()
         xi, yi, zi, mi = self._rows(snk, 4)

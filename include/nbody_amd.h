@@ -89,6 +89,11 @@ int nb_get_acc(nb_ctx* ctx, void* ax, void* ay, void* az);
 int nb_step(nb_ctx* ctx, double dt, int64_t nsteps, double eps, double G);
 /* kinetic and softened potential energy, accumulated in fp64 */
 int nb_energy(nb_ctx* ctx, double eps, double G, double* kinetic, double* potential);
+/* nsteps KDK steps like nb_step, plus the energies after every step: kinetic[k], potential[k] (host arrays of
+ * nsteps doubles, either may be NULL) at the synchronised end of step k. The potential is accumulated inside
+ * the force kernel (SURVEY §8a ⊕3: one extra accumulator per sink instead of a second O(N^2) pass), so an
+ * energy-monitored run costs the same pair evaluations as a plain one. Direct solver only. */
+int nb_step_energy(nb_ctx* ctx, double dt, int64_t nsteps, double eps, double G, double* kinetic, double* potential);
 
 /* ---- device-pointer surface: building blocks for the sink-decomposed multi-GPU path ---- */
 /* acc[i] (+)= G * sum_{j<n_src} m_j (r_j - r_i)/(r_ij^2+eps^2)^{3/2} for i < n_snk.
@@ -97,6 +102,13 @@ int nb_accel_dev(nb_ctx* ctx, int dtype,
                  const void* xi, const void* yi, const void* zi, int64_t n_snk,
                  const void* xs, const void* ys, const void* zs, const void* ms, int64_t n_src,
                  double eps, double G, void* ax, void* ay, void* az, int flags);
+/* nb_accel_dev that also returns phi[i] (+)= sum_{j<n_src} m_j / sqrt(r_ij^2+eps^2) (device double[n_snk], NOT
+ * multiplied by G). No pair is skipped: when sink i is among the sources its own term m_i/eps is included
+ * (eps = 0: coincident pairs contribute nothing) and the caller removes it — see nb_step_energy. */
+int nb_accel_pot_dev(nb_ctx* ctx, int dtype,
+                     const void* xi, const void* yi, const void* zi, int64_t n_snk,
+                     const void* xs, const void* ys, const void* zs, const void* ms, int64_t n_src,
+                     double eps, double G, void* ax, void* ay, void* az, double* phi, int flags);
 /* u_out[0] (+)= sum_i m_i sum_{j != i (by global index)} m_j / sqrt(r_ij^2+eps^2)   (device double;
  * the caller applies -G/2). snk_global0 / src_global0 are the global indices of element 0 of each set. */
 int nb_potential_dev(nb_ctx* ctx, int dtype,

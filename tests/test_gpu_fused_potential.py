@@ -1,0 +1,128 @@
+"""Fused force + potential (SURVEY.md §8a row ⊕3): `nb_accel_pot_dev` / `nb_step_energy` against the separate
+potential kernel, the oracle, and a NumPy direct sum. All calls go through the C-ABI."""
+import numpy as np
+import pytest
+
+import bachelor_thesis_n_body_amd as nb
+from oracle import nbody_oracle as ora
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DTYPES = [np.float32, np.float64]
+TOL = {np.float32: 2e-5, np.float64: 1e-11}
+
+
+def _phi_ref(snk, src, m, eps):
+    d = src[None, :, :] - snk[:, None, :]
+    return (m[None, :] / np.sqrt((d * d).sum(-1) + eps * eps)).sum(1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("uniform", [False, True])
+@pytest.mark.parametrize("n_snk,n_src", [(1, 1), (777, 1500), (3000, 3000), (20000, 4099)])
+def test_accel_pot_dev_matches_direct_sum(dtype, uniform, n_snk, n_src):
+    """phi and acc of the fused kernel; both the one-slab and the split-source launch shapes, ragged tails."""
+    import torch
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    rng = np.random.default_rng(n_snk + n_src)
+    src = rng.normal(size=(n_src, 3)).astype(dtype)
+    snk = rng.normal(size=(n_snk, 3)).astype(dtype)
+    m = (np.full(n_src, 0.37) if uniform else rng.uniform(0.1, 2.0, n_src)).astype(dtype)
+    eps = 0.05
+    k = nb.HipKernels(0)
+    pm = torch.from_numpy(np.vstack([src.T, m[None, :]])).contiguous().cuda()
+    ps = torch.from_numpy(np.ascontiguousarray(snk.T)).cuda()
+    acc = torch.empty((3, n_snk), dtype=tdt, device="cuda")
+    acc0 = torch.empty_like(acc)
+    phi = torch.full((n_snk,), -1.0, dtype=torch.float64, device="cuda")
+    k.accel_pot(ps, n_snk, pm, n_src, eps, 1.5, acc, phi, False, uniform_mass=uniform)
+    k.accel(ps, n_snk, pm, n_src, eps, 1.5, acc0, False, uniform_mass=uniform)
+    torch.cuda.synchronize()
+    ref = _phi_ref(snk.astype(np.float64), src.astype(np.float64), m.astype(np.float64), eps)
+    assert np.abs(phi.cpu().numpy() / ref - 1).max() < TOL[dtype]
+    # the force output of the fused variant is the plain kernel's, bit for bit
+    assert torch.equal(acc, acc0)
+    # accumulate: a second call over the same sources doubles phi
+    k.accel_pot(ps, n_snk, pm, n_src, eps, 1.5, acc, phi, True, uniform_mass=uniform)
+    torch.cuda.synchronize()
+    assert np.abs(phi.cpu().numpy() / (2 * ref) - 1).max() < TOL[dtype]
+    k.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_accel_pot_dev_zero_softening_drops_coincident_pairs(dtype):
+    import torch
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    rng = np.random.default_rng(5)
+    pos = rng.normal(size=(300, 3)).astype(dtype)
+    pos[17] = pos[3]                                  # a truly coincident pair
+    m = rng.uniform(0.5, 1.5, 300).astype(dtype)
+    k = nb.HipKernels(0)
+    pm = torch.from_numpy(np.vstack([pos.T, m[None, :]])).contiguous().cuda()
+    acc = torch.empty((3, 300), dtype=tdt, device="cuda")
+    phi = torch.empty((300,), dtype=torch.float64, device="cuda")
+    k.accel_pot(pm[:3].contiguous(), 300, pm, 300, 0.0, 1.0, acc, phi, False)
+    torch.cuda.synchronize()
+    p = pos.astype(np.float64)
+    d = p[None] - p[:, None]
+    r2 = (d * d).sum(-1)
+    with np.errstate(divide="ignore"):
+        w = np.where(r2 > 0, m.astype(np.float64)[None, :] / np.sqrt(r2), 0.0)
+    got = phi.cpu().numpy()
+    assert np.isfinite(got).all() and np.isfinite(acc.cpu().numpy()).all()
+    assert np.abs(got / w.sum(1) - 1).max() < TOL[dtype]
+    k.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("uniform", [False, True])
+@pytest.mark.parametrize("n,eps", [(2, 0.5), (1000, 0.01), (5000, 0.02), (20000, 0.01), (1000, 0.0)])
+def test_step_energy_equals_step_then_energy(dtype, uniform, n, eps):
+    """Trajectory: identical to nb_step's. Energies: the separate O(N^2) potential / kinetic kernels at every step."""
+    s = nb.plummer_sphere(n, 23, dtype)
+    if not uniform:
+        s.mass[:] = (s.mass * np.random.default_rng(1).uniform(0.5, 1.5, n)).astype(dtype)
+    dt, nsteps = 1 / 512, 4
+    with nb.Engine(n, dtype) as e:
+        e.set_state(s)
+        K, U = e.step_with_energy(dt, nsteps, eps)
+        fused = e.get_state()
+    ks, us = [], []
+    with nb.Engine(n, dtype) as e:
+        e.set_state(s)
+        for _ in range(nsteps):
+            e.step(dt, 1, eps)
+            k, u = e.energy(eps)
+            ks.append(k); us.append(u)
+        ref = e.get_state()
+    np.testing.assert_array_equal(fused.pos, ref.pos)
+    np.testing.assert_array_equal(fused.vel, ref.vel)
+    np.testing.assert_allclose(K, ks, rtol=1e-13)
+    np.testing.assert_allclose(U, us, rtol=3e-6 if dtype == np.float32 else 1e-12)
+
+
+def test_step_energy_matches_oracle_fp64(coracle):
+    s = nb.plummer_sphere(1500, 4, np.float64)
+    o = ora.State(s.pos.copy(), s.vel.copy(), s.mass.copy())
+    with nb.Engine(s.n, np.float64) as e:
+        e.set_state(s)
+        K, U = e.step_with_energy(1 / 256, 3, 0.01)
+    for i in range(3):
+        ora.step(o, 1 / 256, 1, eps=0.01)
+        assert K[i] == pytest.approx(coracle.kinetic(o.vel, o.mass), rel=1e-12)
+        assert U[i] == pytest.approx(coracle.potential(o.pos, o.mass, 0.01), rel=1e-11)
+
+
+def test_step_energy_argument_errors():
+    s = nb.plummer_sphere(256, 1, np.float32)
+    with nb.Engine(s.n, np.float32) as e:
+        with pytest.raises(RuntimeError, match="nb_set_state"):
+            e.step_with_energy(0.01, 1, 0.01)
+        e.set_state(s)
+        with pytest.raises(RuntimeError, match="eps"):
+            e.step_with_energy(0.01, 1, -1.0)
+        e.set_solver("tree", 0.5)
+        with pytest.raises(RuntimeError, match="direct solver"):
+            e.step_with_energy(0.01, 1, 0.01)
+        k, u = (e.set_solver("direct"), e.step_with_energy(0.01, 0, 0.01))[1]
+        assert k.size == 0 and u.size == 0
