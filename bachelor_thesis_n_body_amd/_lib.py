@@ -12,7 +12,8 @@ from pathlib import Path
 NB_F32, NB_F64 = 0, 1
 NB_OK = 0
 NB_ACCUMULATE, NB_UNIFORM_MASS = 1, 2
-NB_SOLVER_DIRECT, NB_SOLVER_TREE = 0, 1
+NB_SOLVER_DIRECT, NB_SOLVER_TREE, NB_SOLVER_EWALD, NB_SOLVER_PM, NB_SOLVER_P3M = 0, 1, 2, 3, 4
+NB_MESH_NO_INTERLACE, NB_MESH_LONG_ONLY, NB_MESH_SHORT_ONLY = 1, 2, 4
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libnbody_amd.so"
@@ -29,6 +30,7 @@ SIGNATURES = {
     "nb_synchronize": (_int, [_vp]),
     "nb_set_solver": (_int, [_vp, _int, _dbl]),
     "nb_set_periodic": (_int, [_vp, _dbl, _dbl, _int]),
+    "nb_set_mesh": (_int, [_vp, _int, _dbl, _int, _dbl, _dbl, _int]),
     "nb_kdk_step": (_int, [_vp, _dbl, _dbl, _dbl, _dbl, _dbl]),
     "nb_set_state": (_int, [_vp] + [_vp] * 7),
     "nb_get_state": (_int, [_vp] + [_vp] * 7),

@@ -76,6 +76,16 @@ class Engine:
         """Cubic periodic box (Ewald summation, uniform background subtracted); boxsize <= 0 switches it off."""
         _lib.check(self._ctx, self._lib.nb_set_periodic(self._ctx, float(boxsize), float(alpha_L), int(kmax)), "nb_set_periodic")
 
+    def set_mesh(self, solver: str, boxsize: float, ngrid: int, scale_cells: float = 1.25, range_scales: float = 4.5,
+                 interlace: bool = True, part: str = "both") -> None:
+        """Periodic box solved with 'pm' or 'p3m' on an ngrid^3 mesh (CONCEPT's `'gravity': 'pm' | 'p3m'`; defaults are its
+        documented short-range parameters). part = 'long' / 'short' evaluates one half of the P3M split only (diagnostics)."""
+        code = {"pm": _lib.NB_SOLVER_PM, "p3m": _lib.NB_SOLVER_P3M}[solver]
+        flags = (0 if interlace else _lib.NB_MESH_NO_INTERLACE) | {"both": 0, "long": _lib.NB_MESH_LONG_ONLY,
+                                                                     "short": _lib.NB_MESH_SHORT_ONLY}[part]
+        _lib.check(self._ctx, self._lib.nb_set_mesh(self._ctx, code, float(boxsize), int(ngrid), float(scale_cells),
+                                                    float(range_scales), flags), "nb_set_mesh")
+
     def kdk_step(self, kick1: float, drift: float, kick2: float, eps: float, G: float = 1.0) -> None:
         """v += a*kick1; x += v*drift; a = a(x); v += a*kick2 (comoving leapfrog with kick = int dt/a, drift = int dt/a^2)."""
         _lib.check(self._ctx, self._lib.nb_kdk_step(self._ctx, kick1, drift, kick2, eps, G), "nb_kdk_step")

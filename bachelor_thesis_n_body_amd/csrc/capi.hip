@@ -3,6 +3,7 @@
 // stream with no host round trip inside nb_step().
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -95,6 +96,7 @@ int nb_destroy(nb_ctx* c) {
   if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
   nb_bh_release(c);
   nb_ewald_release(c);
+  nb_mesh_release(c);
   if (c->state) (void)hipFree(c->state);
   if (c->work) (void)hipFree(c->work);
   if (c->scal) (void)hipFree(c->scal);
@@ -133,6 +135,24 @@ int nb_set_periodic(nb_ctx* c, double boxsize, double alpha_L, int kmax) {
   if (!(boxsize > 0.0)) { c->solver = NB_SOLVER_DIRECT; c->box = 0.0; return NB_OK; }
   if (!(alpha_L > 0.0) || kmax < 1 || kmax > 16) return nb_fail(c, NB_ERR_ARG, "nb_set_periodic: alpha_L must be > 0 and kmax in [1, 16]");
   c->solver = NB_SOLVER_EWALD; c->box = boxsize; c->alphaL = alpha_L; c->kmax = kmax;
+  return NB_OK;
+}
+
+int nb_set_mesh(nb_ctx* c, int solver, double boxsize, int ngrid, double scale_cells, double range_scales, int flags) {
+  if (!c) return NB_ERR_ARG;
+  if (solver != NB_SOLVER_PM && solver != NB_SOLVER_P3M) return nb_fail(c, NB_ERR_ARG, "nb_set_mesh: solver must be NB_SOLVER_PM or NB_SOLVER_P3M");
+  if (!(boxsize > 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_set_mesh: boxsize must be > 0");
+  if (ngrid < 4 || ngrid > 2048) return nb_fail(c, NB_ERR_ARG, "nb_set_mesh: grid size must be in [4, 2048]");
+  if (solver == NB_SOLVER_P3M) {
+    if (!(scale_cells > 0.0) || !(range_scales > 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_set_mesh: split scale and range must be > 0");
+    if (std::floor(ngrid / (scale_cells * range_scales)) < 3.0)
+      return nb_fail(c, NB_ERR_ARG, "nb_set_mesh: the short-range cut-off exceeds a third of the box (grid too coarse); use nb_set_periodic");
+  }
+  if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
+  c->acc_valid = false;
+  c->solver = solver; c->box = boxsize; c->mesh_grid = ngrid; c->mesh_scale = scale_cells; c->mesh_range = range_scales;
+  c->mesh_interlace = (flags & NB_MESH_NO_INTERLACE) ? 0 : 1;
+  c->mesh_parts = (flags & NB_MESH_LONG_ONLY) ? 1 : (flags & NB_MESH_SHORT_ONLY) ? 2 : 3;
   return NB_OK;
 }
 
@@ -185,6 +205,11 @@ static int refresh_acc(nb_ctx* c, double eps, double G, double* phi = nullptr) {
     char* s = reinterpret_cast<char*>(c->state);
     rc = nb_launch_accel_ewald(c, c->dtype, s, s + b, s + 2 * b, s + 3 * b, c->n, c->box, c->alphaL, c->kmax, eps * eps, G,
                                s + 7 * b, s + 8 * b, s + 9 * b);
+  } else if (c->solver == NB_SOLVER_PM || c->solver == NB_SOLVER_P3M) {
+    const size_t b = (size_t)c->n * esize(c->dtype);
+    char* s = reinterpret_cast<char*>(c->state);
+    rc = nb_launch_accel_mesh(c, c->dtype, s, s + b, s + 2 * b, s + 3 * b, c->n, c->box, c->mesh_grid, c->mesh_scale, c->mesh_range,
+                              c->solver == NB_SOLVER_P3M, c->mesh_interlace, c->mesh_parts, eps * eps, G, s + 7 * b, s + 8 * b, s + 9 * b);
   } else if (c->solver == NB_SOLVER_TREE) {
     if (c->dtype != NB_F32) return nb_fail(c, NB_ERR_ARG, "the tree solver is fp32 only");
     float* s = reinterpret_cast<float*>(c->state);
@@ -277,7 +302,7 @@ int nb_step(nb_ctx* c, double dt, int64_t nsteps, double eps, double G) {
     // step k: [closing half-kick of step k-1, fused] opening half-kick, drift; force; (closing kick deferred)
     rc = nb_launch_kick_drift(c, c->dtype, x, y, z, vx, vy, vz, ax, ay, az, c->n, k == 0 ? 0.0 : h, h, dt);
     if (rc) return rc;
-    if (c->solver == NB_SOLVER_EWALD) { rc = nb_launch_wrap(c, c->dtype, x, y, z, c->n, c->box); if (rc) return rc; }
+    if (c->solver >= NB_SOLVER_EWALD) { rc = nb_launch_wrap(c, c->dtype, x, y, z, c->n, c->box); if (rc) return rc; }
     rc = refresh_acc(c, eps, G); if (rc) return rc;
   }
   rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, h); if (rc) return rc;
@@ -297,7 +322,7 @@ int nb_kdk_step(nb_ctx* c, double kick1, double drift, double kick2, double eps,
   void *ax = s + 7 * b, *ay = s + 8 * b, *az = s + 9 * b;
   rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, kick1); if (rc) return rc;
   rc = nb_launch_drift(c, c->dtype, x, y, z, vx, vy, vz, c->n, drift); if (rc) return rc;
-  if (c->solver == NB_SOLVER_EWALD) { rc = nb_launch_wrap(c, c->dtype, x, y, z, c->n, c->box); if (rc) return rc; }
+  if (c->solver >= NB_SOLVER_EWALD) { rc = nb_launch_wrap(c, c->dtype, x, y, z, c->n, c->box); if (rc) return rc; }
   rc = refresh_acc(c, eps, G); if (rc) return rc;
   rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, kick2); if (rc) return rc;
   NB_HIP(c, hipStreamSynchronize(c->stream));

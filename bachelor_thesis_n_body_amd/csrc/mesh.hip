@@ -1,0 +1,460 @@
+// Particle-mesh (PM) and particle-particle-particle-mesh (P3M) gravity in a periodic cube — SURVEY.md §8f row 4
+// ("then periodic/comoving PP (Ewald) and PM/P3M long-range via hipFFT"). These are the solvers the reference's farms
+// actually select: `select_forces = {'matter': {'gravity': 'p3m'}}` with `potential_options` gridsize = cbrt(N),
+// 'Fourier' differentiation, CIC interpolation, deconvolve (True, True), interlace (True, True)
+// (TheFeedingPipeline/NN.param:53-82, SnapVsPK/Uncertain.param:66-95); `'gravity': 'pm'` in
+// Different_Sizes/Giant.param:28-68. CONCEPT's source is not in the reference, so this follows the published method
+// (Hockney & Eastwood; CONCEPT's documented defaults: split scale r_s = 1.25 cells, short-range cut-off 4.5 r_s).
+//
+// Force split (alpha = 1 / (2 r_s)), identical in form to the Ewald split of ewald.hip, so P3M -> Ewald as h -> 0:
+//   long range :  phi_k = -4 pi G rho_k / k^2 * exp(-k^2 r_s^2)        (PM: no Gaussian factor, no short range)
+//   short range:  a_i += G m_j d [ (r^2+eps^2)^{-3/2} - (erf(alpha r) - 2 alpha r/sqrt(pi) e^{-alpha^2 r^2}) / r^3 ],  r < r_cut
+//
+// Long-range pipeline, all grids fp64, ONE complex-to-complex forward FFT and THREE inverse FFTs per evaluation:
+//   deposit    CIC mass assignment with global_atomic_add_f64; lattice 1 -> real part, the lattice shifted by half a
+//              cell (interlacing) -> imaginary part of the same complex grid                        [HBM/atomic bound]
+//   FFT        hipFFT Z2Z forward; the two real fields are separated with the Hermitian symmetry in the k-space kernel
+//   k-space    rho_k = (A_k + B_k e^{-i theta})/2, times Green's function, CIC deconvolution (twice: deposit and
+//              interpolation), i k differentiation; Nyquist planes are zeroed. The six real output fields
+//              (g_x, g_y, g_z on both lattices) are packed pairwise into three complex grids      [HBM bound, 16 B in, 48 B out per mode]
+//   inverse    3 x hipFFT Z2Z backward
+//   gather     CIC interpolation of both lattices to the particles, averaged                         [HBM gather bound]
+// Short range: particles are counting-sorted (rocPRIM radix sort) into cells of side >= r_cut; one 128-thread block
+// per (cell, 128-sink chunk) walks the 27 neighbour cells, source tiles staged through LDS and read back as
+// wave-uniform broadcasts (the accel_f32.hip pattern); the periodic image is a per-neighbour-cell shift, not a
+// per-pair minimum image.                                                                           [VALU bound]
+#include "nb_common.h"
+#include "../../include/nbody_amd.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <hipfft/hipfft.h>
+
+struct nb_mesh_state {
+  int ngrid = 0;
+  bool have_fft = false;
+  hipfftHandle fft = 0;
+  hipStream_t fft_stream = nullptr;
+  hipfftDoubleComplex* grid[4] = {nullptr, nullptr, nullptr, nullptr};   // density (two lattices) + 3 packed force grids
+  // short range
+  int64_t n_alloc = 0;
+  int esz = 0;
+  uint32_t *keys = nullptr, *keys_s = nullptr, *idx = nullptr, *idx_s = nullptr;
+  void* sorted = nullptr;            // {x, y, z, m} per particle in cell order, positions wrapped into [0, L)
+  int ncell3_alloc = 0;
+  int *cell_start = nullptr, *chunk_cnt = nullptr, *chunk_off = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+};
+
+namespace {
+
+constexpr int SRB = 128;   // short-range block = sink chunk = source tile
+
+struct d4 { double x, y, z, w; };
+
+__device__ inline int wrap_index(long long i, int n) {
+  int r = (int)(i % n);
+  return r < 0 ? r + n : r;
+}
+
+// CIC deposit of particle masses onto one lattice; `shift` = 0 (lattice 1, real part) or 0.5 (lattice displaced by half
+// a cell along every axis, imaginary part). grid is the complex grid viewed as doubles: element 2*cell + comp.
+template <typename T>
+__global__ void __launch_bounds__(256)
+mesh_deposit_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, const T* __restrict__ m,
+                    int64_t n, double invh, int N, double shift, int comp, double* __restrict__ grid) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    const double ux = (double)x[p] * invh - shift, uy = (double)y[p] * invh - shift, uz = (double)z[p] * invh - shift;
+    const double fx = floor(ux), fy = floor(uy), fz = floor(uz);
+    const double wx1 = ux - fx, wy1 = uy - fy, wz1 = uz - fz;
+    const int i0 = wrap_index((long long)fx, N), j0 = wrap_index((long long)fy, N), k0 = wrap_index((long long)fz, N);
+    const int i1 = i0 + 1 == N ? 0 : i0 + 1, j1 = j0 + 1 == N ? 0 : j0 + 1, k1 = k0 + 1 == N ? 0 : k0 + 1;
+    const double mass = (double)m[p];
+    const double wx[2] = {(1.0 - wx1) * mass, wx1 * mass}, wy[2] = {1.0 - wy1, wy1}, wz[2] = {1.0 - wz1, wz1};
+    const int ii[2] = {i0, i1}, jj[2] = {j0, j1}, kk[2] = {k0, k1};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          atomicAdd(&grid[2 * (((size_t)ii[a] * N + jj[b]) * N + kk[c]) + comp], (wx[a] * wy[b]) * wz[c]);
+  }
+}
+
+__device__ inline double inv_sinc2(double t) {   // 1 / sinc(t)^2, sinc(t) = sin(t)/t
+  if (fabs(t) < 1e-8) return 1.0;
+  const double s = t / sin(t);
+  return s * s;
+}
+
+// One thread per mode. in = FFT of (lattice-1 density) + i (lattice-2 density); out: three complex grids holding
+// (g_x + i g_y), (g_z + i g'_x), (g'_y + i g'_z) in k-space, primes = sampled on the shifted lattice.
+// fac = 4 pi G / L^3 (deposit is mass per cell, the unnormalised inverse FFT supplies the sum; 1/N^3 and 1/h^3 combine).
+__global__ void __launch_bounds__(256)
+mesh_kspace_kernel(const hipfftDoubleComplex* __restrict__ in, hipfftDoubleComplex* __restrict__ o1,
+                   hipfftDoubleComplex* __restrict__ o2, hipfftDoubleComplex* __restrict__ o3, int N, double L,
+                   double rs, double fac, int interlace, int gaussian) {
+  const size_t cells = (size_t)N * N * N;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= cells) return;
+  const int iz = (int)(idx % N), iy = (int)((idx / N) % N), ix = (int)(idx / ((size_t)N * N));
+  const int half = N / 2;
+  const bool nyq = (N % 2 == 0) && (ix == half || iy == half || iz == half);
+  hipfftDoubleComplex z0 = {0.0, 0.0};
+  if ((ix == 0 && iy == 0 && iz == 0) || nyq) { o1[idx] = z0; o2[idx] = z0; o3[idx] = z0; return; }
+  const int mx = ix ? N - ix : 0, my = iy ? N - iy : 0, mz = iz ? N - iz : 0;
+  const hipfftDoubleComplex C = in[idx], Cm = in[((size_t)mx * N + my) * N + mz];
+  // A = (C + conj(Cm)) / 2,  B = (C - conj(Cm)) / (2 i)
+  const double Ar = 0.5 * (C.x + Cm.x), Ai = 0.5 * (C.y - Cm.y);
+  const double Br = 0.5 * (C.y + Cm.y), Bi = -0.5 * (C.x - Cm.x);
+  const double dk = 2.0 * 3.14159265358979323846 / L, h = L / N;
+  const double kx = dk * (ix <= half ? ix : ix - N), ky = dk * (iy <= half ? iy : iy - N), kz = dk * (iz <= half ? iz : iz - N);
+  const double theta = 0.5 * h * (kx + ky + kz);
+  double st, ct;
+  sincos(theta, &st, &ct);
+  double rr = Ar, ri = Ai;
+  if (interlace) {   // (A + B e^{-i theta}) / 2
+    rr = 0.5 * (Ar + Br * ct + Bi * st);
+    ri = 0.5 * (Ai + Bi * ct - Br * st);
+  }
+  const double k2 = kx * kx + ky * ky + kz * kz;
+  double g = fac / k2;
+  if (gaussian) g *= exp(-k2 * rs * rs);
+  const double dec = inv_sinc2(0.5 * kx * h) * inv_sinc2(0.5 * ky * h) * inv_sinc2(0.5 * kz * h);   // 1 / W_CIC
+  g *= dec * dec;                                                                                      // deposit and interpolation
+  // g_c = i k_c g rho:  i (rr + i ri) = -ri + i rr
+  const double pr = -ri * g, pi = rr * g;
+  const double gxr = kx * pr, gxi = kx * pi, gyr = ky * pr, gyi = ky * pi, gzr = kz * pr, gzi = kz * pi;
+  // primes: times e^{+i theta}
+  const double qr = pr * ct - pi * st, qi = pr * st + pi * ct;
+  const double hxr = kx * qr, hxi = kx * qi, hyr = ky * qr, hyi = ky * qi, hzr = kz * qr, hzi = kz * qi;
+  // pack P + i Q = (Pr - Qi) + i (Pi + Qr)
+  o1[idx] = hipfftDoubleComplex{gxr - gyi, gxi + gyr};
+  o2[idx] = hipfftDoubleComplex{gzr - hxi, gzi + hxr};
+  o3[idx] = hipfftDoubleComplex{hyr - hzi, hyi + hzr};
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+mesh_gather_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, int64_t n, double invh,
+                   int N, const double* __restrict__ f1, const double* __restrict__ f2, const double* __restrict__ f3,
+                   int interlace, T* __restrict__ ax, T* __restrict__ ay, T* __restrict__ az) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int lat = 0; lat < (interlace ? 2 : 1); ++lat) {
+      const double shift = lat ? 0.5 : 0.0;
+      const double ux = (double)x[p] * invh - shift, uy = (double)y[p] * invh - shift, uz = (double)z[p] * invh - shift;
+      const double fx = floor(ux), fy = floor(uy), fz = floor(uz);
+      const double wx1 = ux - fx, wy1 = uy - fy, wz1 = uz - fz;
+      const int i0 = wrap_index((long long)fx, N), j0 = wrap_index((long long)fy, N), k0 = wrap_index((long long)fz, N);
+      const int i1 = i0 + 1 == N ? 0 : i0 + 1, j1 = j0 + 1 == N ? 0 : j0 + 1, k1 = k0 + 1 == N ? 0 : k0 + 1;
+      const double wx[2] = {1.0 - wx1, wx1}, wy[2] = {1.0 - wy1, wy1}, wz[2] = {1.0 - wz1, wz1};
+      const int ii[2] = {i0, i1}, jj[2] = {j0, j1}, kk[2] = {k0, k1};
+      // lattice 1: g_x = Re f1, g_y = Im f1, g_z = Re f2;   lattice 2: g_x = Im f2, g_y = Re f3, g_z = Im f3
+      const double* gx = lat ? f2 + 1 : f1;
+      const double* gy = lat ? f3 : f1 + 1;
+      const double* gz = lat ? f3 + 1 : f2;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const size_t cell = 2 * (((size_t)ii[a] * N + jj[b]) * N + kk[c]);
+            const double w = (wx[a] * wy[b]) * wz[c];
+            sx += w * gx[cell]; sy += w * gy[cell]; sz += w * gz[cell];
+          }
+    }
+    const double s = interlace ? 0.5 : 1.0;
+    ax[p] = (T)(s * sx); ay[p] = (T)(s * sy); az[p] = (T)(s * sz);
+  }
+}
+
+/* ------------------------------------------------------------------ short range ---- */
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+cell_key_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, int64_t n, double L,
+                int nc, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const double invL = 1.0 / L;
+  double px = (double)x[p], py = (double)y[p], pz = (double)z[p];
+  px -= L * floor(px * invL); py -= L * floor(py * invL); pz -= L * floor(pz * invL);
+  const double s = nc * invL;
+  const int cx = min(nc - 1, max(0, (int)(px * s))), cy = min(nc - 1, max(0, (int)(py * s))), cz = min(nc - 1, max(0, (int)(pz * s)));
+  keys[p] = (uint32_t)((cx * nc + cy) * nc + cz);
+  idx[p] = (uint32_t)p;
+}
+
+template <typename T, typename V4>
+__global__ void __launch_bounds__(256)
+sort_gather_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, const T* __restrict__ m,
+                   const uint32_t* __restrict__ idx_s, int64_t n, double L, V4* __restrict__ sorted) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t q = idx_s[p];
+  const double invL = 1.0 / L;
+  double px = (double)x[q], py = (double)y[q], pz = (double)z[q];
+  px -= L * floor(px * invL); py -= L * floor(py * invL); pz -= L * floor(pz * invL);
+  V4 v; v.x = (T)px; v.y = (T)py; v.z = (T)pz; v.w = m[q];
+  sorted[p] = v;
+}
+
+// cell_start[c] = first sorted position whose key >= c, for c = 0 .. ncell3 (cell_start[ncell3] = n)
+__global__ void __launch_bounds__(256)
+cell_start_kernel(const uint32_t* __restrict__ keys_s, int64_t n, int ncell3, int* __restrict__ cell_start) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > n) return;
+  const int lo = p == 0 ? 0 : (int)keys_s[p - 1] + 1;
+  const int hi = p == n ? ncell3 : (int)keys_s[p];
+  for (int c = lo; c <= hi; ++c) cell_start[c] = (int)p;
+}
+
+__global__ void __launch_bounds__(256)
+chunk_count_kernel(const int* __restrict__ cell_start, int ncell3, int* __restrict__ cnt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > ncell3) return;
+  cnt[c] = c < ncell3 ? (cell_start[c + 1] - cell_start[c] + SRB - 1) / SRB : 0;
+}
+
+// erfc-split pair factor:  (r^2+eps^2)^{-3/2} - (erf(a r) - 2 a r/sqrt(pi) e^{-a^2 r^2}) / r^3
+__device__ inline float sr_factor(float r2, float eps2, float alpha, float c2, float a2l) {
+  const float rinv = r2 > 0.f ? __builtin_amdgcn_rsqf(r2) : 0.f;
+  const float r = r2 * rinv;
+  const float u = alpha * r;
+  const float t = __builtin_amdgcn_exp2f(a2l * r2);
+  const float q = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));           // Abramowitz-Stegun 7.1.26, |err| < 1.5e-7
+  const float poly = q * fmaf(q, fmaf(q, fmaf(q, fmaf(q, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float erf_u = fmaf(-poly, t, 1.0f);
+  const float lng = (erf_u - c2 * r * t) * (rinv * rinv * rinv);
+  const float sinv = __builtin_amdgcn_rsqf(r2 + eps2);
+  const float soft = r2 > 0.f ? sinv * sinv * sinv : 0.f;
+  return soft - lng;
+}
+__device__ inline double sr_factor(double r2, double eps2, double alpha, double c2, double /*unused*/) {
+  if (!(r2 > 0.0)) return 0.0;
+  const double r = sqrt(r2), u = alpha * r, rinv = 1.0 / r;
+  const double r2s = r2 + eps2;
+  const double soft = 1.0 / (r2s * sqrt(r2s));
+  const double lng = (erf(u) - c2 * r * exp(-u * u)) * rinv * rinv * rinv;
+  return soft - lng;
+}
+
+template <typename T, typename V4>
+__global__ void __launch_bounds__(SRB)
+short_range_kernel(const V4* __restrict__ sorted, const int* __restrict__ cell_start, const int* __restrict__ chunk_off,
+                   int ncell3, int nc, T L, T alpha, T rcut2, T eps2, double G, const uint32_t* __restrict__ idx_s,
+                   T* __restrict__ ax, T* __restrict__ ay, T* __restrict__ az) {
+  __shared__ V4 tile[SRB];
+  const int total = chunk_off[ncell3];
+  const int w = blockIdx.x;
+  if (w >= total) return;                       // the grid is an upper bound on the number of chunks
+  // cell = last c with chunk_off[c] <= w  (block-uniform binary search)
+  int lo = 0, hi = ncell3;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= w) lo = mid; else hi = mid; }
+  const int cell = lo, chunk = w - chunk_off[cell];
+  const int cz = cell % nc, cy = (cell / nc) % nc, cx = cell / (nc * nc);
+  const int s0 = cell_start[cell], s1 = cell_start[cell + 1];
+  const int i = s0 + chunk * SRB + (int)threadIdx.x;
+  const bool live = i < s1;
+  const V4 me = sorted[live ? i : s1 - 1];
+  const T c2 = (T)2 * alpha * (T)0.5641895835477563, a2l = -alpha * alpha * (T)1.4426950408889634;
+  double tx = 0.0, ty = 0.0, tz = 0.0;
+  for (int nb = 0; nb < 27; ++nb) {
+    const int ox = nb / 9 - 1, oy = (nb / 3) % 3 - 1, oz = nb % 3 - 1;
+    int qx = cx + ox, qy = cy + oy, qz = cz + oz;
+    T shx = 0, shy = 0, shz = 0;                // periodic image of the whole neighbour cell
+    if (qx < 0) { qx += nc; shx = -L; } else if (qx >= nc) { qx -= nc; shx = L; }
+    if (qy < 0) { qy += nc; shy = -L; } else if (qy >= nc) { qy -= nc; shy = L; }
+    if (qz < 0) { qz += nc; shz = -L; } else if (qz >= nc) { qz -= nc; shz = L; }
+    const int q = (qx * nc + qy) * nc + qz;
+    const int b0 = cell_start[q], b1 = cell_start[q + 1];
+    for (int j0 = b0; j0 < b1; j0 += SRB) {
+      __syncthreads();
+      const int j = j0 + (int)threadIdx.x;
+      if (j < b1) {
+        V4 s = sorted[j];
+        s.x += shx; s.y += shy; s.z += shz;
+        tile[threadIdx.x] = s;
+      }
+      __syncthreads();
+      const int cnt = min(SRB, b1 - j0);
+      T fx = 0, fy = 0, fz = 0;
+#pragma unroll 4
+      for (int e = 0; e < cnt; ++e) {
+        const V4 s = tile[e];                   // wave-uniform address: LDS broadcast
+        const T dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
+        const T r2 = dx * dx + dy * dy + dz * dz;
+        T f = s.w * sr_factor(r2, eps2, alpha, c2, a2l);
+        f = r2 < rcut2 ? f : (T)0;
+        fx += f * dx; fy += f * dy; fz += f * dz;
+      }
+      tx += (double)fx; ty += (double)fy; tz += (double)fz;
+    }
+  }
+  if (live) {
+    const uint32_t o = idx_s[i];
+    ax[o] += (T)(G * tx); ay[o] += (T)(G * ty); az[o] += (T)(G * tz);
+  }
+}
+
+inline int stream_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+#define M_FFT(c, call) do { hipfftResult r_ = (call); if (r_ != HIPFFT_SUCCESS) \
+  return nb_fail((c), NB_ERR_HIP, std::string(#call) + ": hipfft error " + std::to_string((int)r_)); } while (0)
+
+int ensure_grids(nb_ctx* c, nb_mesh_state& s, int ngrid) {
+  if (s.ngrid == ngrid && s.have_fft && s.fft_stream == c->stream) return NB_OK;
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  if (s.ngrid != ngrid) {
+    for (auto& g : s.grid) if (g) { (void)hipFree(g); g = nullptr; }
+    if (s.have_fft) { (void)hipfftDestroy(s.fft); s.have_fft = false; }
+    const size_t bytes = (size_t)ngrid * ngrid * ngrid * sizeof(hipfftDoubleComplex);
+    for (auto& g : s.grid) NB_HIP(c, hipMalloc((void**)&g, bytes));
+    M_FFT(c, hipfftPlan3d(&s.fft, ngrid, ngrid, ngrid, HIPFFT_Z2Z));
+    s.have_fft = true;
+    s.ngrid = ngrid;
+  }
+  M_FFT(c, hipfftSetStream(s.fft, c->stream));
+  s.fft_stream = c->stream;
+  return NB_OK;
+}
+
+int ensure_cells(nb_ctx* c, nb_mesh_state& s, int64_t n, int esz, int ncell3) {
+  if (s.n_alloc < n || s.esz != esz) {
+    NB_HIP(c, hipStreamSynchronize(c->stream));
+    for (void* p : {(void*)s.keys, (void*)s.keys_s, (void*)s.idx, (void*)s.idx_s, s.sorted}) if (p) (void)hipFree(p);
+    s.keys = s.keys_s = s.idx = s.idx_s = nullptr; s.sorted = nullptr;
+    NB_HIP(c, hipMalloc((void**)&s.keys, (size_t)n * 4)); NB_HIP(c, hipMalloc((void**)&s.keys_s, (size_t)n * 4));
+    NB_HIP(c, hipMalloc((void**)&s.idx, (size_t)n * 4)); NB_HIP(c, hipMalloc((void**)&s.idx_s, (size_t)n * 4));
+    NB_HIP(c, hipMalloc(&s.sorted, (size_t)n * 4 * (size_t)esz));
+    s.n_alloc = n; s.esz = esz;
+    if (s.tmp) { (void)hipFree(s.tmp); s.tmp = nullptr; s.tmp_bytes = 0; }
+  }
+  if (s.ncell3_alloc < ncell3) {
+    NB_HIP(c, hipStreamSynchronize(c->stream));
+    for (int* p : {s.cell_start, s.chunk_cnt, s.chunk_off}) if (p) (void)hipFree(p);
+    NB_HIP(c, hipMalloc((void**)&s.cell_start, ((size_t)ncell3 + 1) * 4));
+    NB_HIP(c, hipMalloc((void**)&s.chunk_cnt, ((size_t)ncell3 + 1) * 4));
+    NB_HIP(c, hipMalloc((void**)&s.chunk_off, ((size_t)ncell3 + 1) * 4));
+    s.ncell3_alloc = ncell3;
+    if (s.tmp) { (void)hipFree(s.tmp); s.tmp = nullptr; s.tmp_bytes = 0; }
+  }
+  if (!s.tmp) {
+    size_t t1 = 0, t2 = 0;
+    NB_HIP(c, rocprim::radix_sort_pairs((void*)nullptr, t1, s.keys, s.keys_s, s.idx, s.idx_s, (size_t)s.n_alloc, 0, 32, c->stream));
+    NB_HIP(c, rocprim::exclusive_scan((void*)nullptr, t2, s.chunk_cnt, s.chunk_off, 0, (size_t)s.ncell3_alloc + 1, rocprim::plus<int>(), c->stream));
+    s.tmp_bytes = t1 > t2 ? t1 : t2;
+    if (s.tmp_bytes < 256) s.tmp_bytes = 256;
+    NB_HIP(c, hipMalloc(&s.tmp, s.tmp_bytes));
+  }
+  return NB_OK;
+}
+
+template <typename T, typename V4>
+int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z, const T* m, int64_t n, double L, int nc,
+                double alpha, double rcut, double eps2, double G, T* ax, T* ay, T* az) {
+  const int ncell3 = nc * nc * nc;
+  int rc = ensure_cells(c, s, n, (int)sizeof(T), ncell3);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
+  const int nb = (int)((n + 255) / 256);
+  cell_key_kernel<T><<<nb, 256, 0, st>>>(x, y, z, n, L, nc, s.keys, s.idx);
+  NB_HIP(c, hipGetLastError());
+  int bits = 1; while ((1u << bits) < (unsigned)ncell3) ++bits;
+  size_t tb = s.tmp_bytes;
+  NB_HIP(c, rocprim::radix_sort_pairs(s.tmp, tb, s.keys, s.keys_s, s.idx, s.idx_s, (size_t)n, 0, (unsigned)bits, st));
+  sort_gather_kernel<T, V4><<<nb, 256, 0, st>>>(x, y, z, m, s.idx_s, n, L, (V4*)s.sorted);
+  NB_HIP(c, hipGetLastError());
+  cell_start_kernel<<<(int)((n + 1 + 255) / 256), 256, 0, st>>>(s.keys_s, n, ncell3, s.cell_start);
+  NB_HIP(c, hipGetLastError());
+  chunk_count_kernel<<<(ncell3 + 1 + 255) / 256, 256, 0, st>>>(s.cell_start, ncell3, s.chunk_cnt);
+  NB_HIP(c, hipGetLastError());
+  tb = s.tmp_bytes;
+  NB_HIP(c, rocprim::exclusive_scan(s.tmp, tb, s.chunk_cnt, s.chunk_off, 0, (size_t)ncell3 + 1, rocprim::plus<int>(), st));
+  const int64_t max_chunks = (int64_t)ncell3 + n / SRB + 1;     // sum_c ceil(n_c / SRB) <= ncell3 + n / SRB
+  short_range_kernel<T, V4><<<(unsigned)max_chunks, SRB, 0, st>>>((const V4*)s.sorted, s.cell_start, s.chunk_off, ncell3, nc,
+                                                                   (T)L, (T)alpha, (T)(rcut * rcut), (T)eps2, G, s.idx_s,
+                                                                   ax, ay, az);
+  NB_HIP(c, hipGetLastError());
+  return NB_OK;
+}
+
+}  // namespace
+
+void nb_mesh_release(nb_ctx* c) {
+  if (!c->mesh) return;
+  nb_mesh_state& s = *c->mesh;
+  for (auto& g : s.grid) if (g) (void)hipFree(g);
+  if (s.have_fft) (void)hipfftDestroy(s.fft);
+  for (void* p : {(void*)s.keys, (void*)s.keys_s, (void*)s.idx, (void*)s.idx_s, s.sorted, (void*)s.cell_start,
+                  (void*)s.chunk_cnt, (void*)s.chunk_off, s.tmp})
+    if (p) (void)hipFree(p);
+  delete c->mesh;
+  c->mesh = nullptr;
+}
+
+// parts: bit 0 = long range (mesh), bit 1 = short range (cells). acc is overwritten.
+int nb_launch_accel_mesh(nb_ctx* c, int dtype, const void* x, const void* y, const void* z, const void* m, int64_t n,
+                         double L, int ngrid, double rs_cells, double rcut_rs, int p3m, int interlace, int parts,
+                         double eps2, double G, void* ax, void* ay, void* az) {
+  if (n <= 0) return NB_OK;
+  if (n >= (1ll << 31)) return nb_fail(c, NB_ERR_ARG, "mesh solver: n must be < 2^31");
+  if (ngrid < 4 || ngrid > 2048) return nb_fail(c, NB_ERR_ARG, "mesh solver: grid size must be in [4, 2048]");
+  if (!c->mesh) c->mesh = new nb_mesh_state();
+  nb_mesh_state& s = *c->mesh;
+  hipStream_t st = c->stream;
+  const double h = L / ngrid, rs = rs_cells * h, rcut = rcut_rs * rs;
+  const size_t esz = dtype == NB_F32 ? 4 : 8;
+  if (parts & 1) {
+    int rc = ensure_grids(c, s, ngrid);
+    if (rc) return rc;
+    const size_t cells = (size_t)ngrid * ngrid * ngrid;
+    NB_HIP(c, hipMemsetAsync(s.grid[0], 0, cells * sizeof(hipfftDoubleComplex), st));
+    for (int lat = 0; lat < (interlace ? 2 : 1); ++lat) {
+      if (dtype == NB_F32)
+        mesh_deposit_kernel<float><<<stream_grid(n), 256, 0, st>>>((const float*)x, (const float*)y, (const float*)z, (const float*)m,
+                                                                   n, 1.0 / h, ngrid, lat ? 0.5 : 0.0, lat, (double*)s.grid[0]);
+      else
+        mesh_deposit_kernel<double><<<stream_grid(n), 256, 0, st>>>((const double*)x, (const double*)y, (const double*)z, (const double*)m,
+                                                                    n, 1.0 / h, ngrid, lat ? 0.5 : 0.0, lat, (double*)s.grid[0]);
+      NB_HIP(c, hipGetLastError());
+    }
+    M_FFT(c, hipfftExecZ2Z(s.fft, s.grid[0], s.grid[0], HIPFFT_FORWARD));
+    const double fac = 4.0 * 3.14159265358979323846 * G / (L * L * L);
+    mesh_kspace_kernel<<<(unsigned)((cells + 255) / 256), 256, 0, st>>>(s.grid[0], s.grid[1], s.grid[2], s.grid[3], ngrid, L, rs, fac,
+                                                                        interlace, p3m);
+    NB_HIP(c, hipGetLastError());
+    for (int g = 1; g <= (interlace ? 3 : 2); ++g) M_FFT(c, hipfftExecZ2Z(s.fft, s.grid[g], s.grid[g], HIPFFT_BACKWARD));
+    if (dtype == NB_F32)
+      mesh_gather_kernel<float><<<stream_grid(n), 256, 0, st>>>((const float*)x, (const float*)y, (const float*)z, n, 1.0 / h, ngrid,
+                                                                (const double*)s.grid[1], (const double*)s.grid[2], (const double*)s.grid[3],
+                                                                interlace, (float*)ax, (float*)ay, (float*)az);
+    else
+      mesh_gather_kernel<double><<<stream_grid(n), 256, 0, st>>>((const double*)x, (const double*)y, (const double*)z, n, 1.0 / h, ngrid,
+                                                                 (const double*)s.grid[1], (const double*)s.grid[2], (const double*)s.grid[3],
+                                                                 interlace, (double*)ax, (double*)ay, (double*)az);
+    NB_HIP(c, hipGetLastError());
+  } else {
+    NB_HIP(c, hipMemsetAsync(ax, 0, (size_t)n * esz, st));
+    NB_HIP(c, hipMemsetAsync(ay, 0, (size_t)n * esz, st));
+    NB_HIP(c, hipMemsetAsync(az, 0, (size_t)n * esz, st));
+  }
+  if (p3m && (parts & 2)) {
+    const int nc = (int)floor(L / rcut);
+    if (nc < 3) return nb_fail(c, NB_ERR_ARG, "p3m: the short-range cut-off exceeds a third of the box (grid too coarse); use the Ewald solver");
+    if ((double)nc * nc * nc > 2.0e9) return nb_fail(c, NB_ERR_ARG, "p3m: too many short-range cells");
+    const double alpha = 1.0 / (2.0 * rs);
+    if (dtype == NB_F32)
+      return short_range<float, float4>(c, s, (const float*)x, (const float*)y, (const float*)z, (const float*)m, n, L, nc, alpha,
+                                        rcut, eps2, G, (float*)ax, (float*)ay, (float*)az);
+    return short_range<double, d4>(c, s, (const double*)x, (const double*)y, (const double*)z, (const double*)m, n, L, nc, alpha,
+                                   rcut, eps2, G, (double*)ax, (double*)ay, (double*)az);
+  }
+  return NB_OK;
+}

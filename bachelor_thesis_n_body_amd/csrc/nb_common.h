@@ -7,6 +7,7 @@
 
 struct nb_bh_state;   // Barnes-Hut buffers (bh.hip)
 struct nb_ewald_state;   // k-vector table and structure factors (ewald.hip)
+struct nb_mesh_state;    // PM / P3M grids, FFT plan and cell lists (mesh.hip)
 
 struct nb_ctx {
   int device = 0;
@@ -35,6 +36,9 @@ struct nb_ctx {
   double theta = 0.5;
   nb_bh_state* bh = nullptr;
   nb_ewald_state* ewald = nullptr;
+  nb_mesh_state* mesh = nullptr;
+  int mesh_grid = 0, mesh_interlace = 1, mesh_parts = 3;   // NB_SOLVER_PM / NB_SOLVER_P3M (nb_set_mesh)
+  double mesh_scale = 1.25, mesh_range = 4.5;              // r_s in cells, cut-off in r_s
   double box = 0.0, alphaL = 6.2;   // periodic cube edge and Ewald splitting (NB_SOLVER_EWALD)
   int kmax = 7;
   std::string err;
@@ -66,6 +70,10 @@ int nb_launch_accel_ewald(nb_ctx* c, int dtype, const void* x, const void* y, co
                           double L, double alphaL, int kmax, double eps2, double G, void* ax, void* ay, void* az);
 int nb_launch_wrap(nb_ctx* c, int dtype, void* x, void* y, void* z, int64_t n, double L);
 void nb_ewald_release(nb_ctx* c);
+int nb_launch_accel_mesh(nb_ctx* c, int dtype, const void* x, const void* y, const void* z, const void* m, int64_t n,
+                         double L, int ngrid, double rs_cells, double rcut_rs, int p3m, int interlace, int parts,
+                         double eps2, double G, void* ax, void* ay, void* az);
+void nb_mesh_release(nb_ctx* c);
 void nb_bh_release(nb_ctx* c);
 int nb_bh_check(nb_ctx* c);   // call after a stream sync
 int nb_launch_potential_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, const float* mi,

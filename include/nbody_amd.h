@@ -36,7 +36,13 @@ typedef struct nb_ctx nb_ctx;
 
 enum { NB_F32 = 0, NB_F64 = 1 };
 /* force solvers selectable per context (nb_set_solver) */
-enum { NB_SOLVER_DIRECT = 0, NB_SOLVER_TREE = 1, NB_SOLVER_EWALD = 2 };
+enum { NB_SOLVER_DIRECT = 0, NB_SOLVER_TREE = 1, NB_SOLVER_EWALD = 2, NB_SOLVER_PM = 3, NB_SOLVER_P3M = 4 };
+/* flags of nb_set_mesh */
+enum {
+  NB_MESH_NO_INTERLACE = 1, /* one lattice instead of two half-cell-shifted ones */
+  NB_MESH_LONG_ONLY = 2,    /* diagnostics: only the mesh part of a P3M force */
+  NB_MESH_SHORT_ONLY = 4    /* diagnostics: only the cell-list part of a P3M force */
+};
 /* flags of nb_accel_dev */
 enum {
   NB_ACCUMULATE = 1,   /* add to the existing ax/ay/az instead of overwriting (source chunks arriving hop by hop) */
@@ -72,6 +78,15 @@ int nb_set_solver(nb_ctx* ctx, int solver, double theta);
  * erfc approximation with fp64-flushed fp32 sums (~5x faster). Positions are wrapped into [0, boxsize)
  * after every drift. boxsize <= 0 returns to the isolated direct sum. Suggested alpha_L = 6.2, kmax = 7 (error ~1e-5). */
 int nb_set_periodic(nb_ctx* ctx, double boxsize, double alpha_L, int kmax);
+/* periodic cubic box solved on a mesh — the solvers the reference's parameter files select with
+ * `select_forces = {'matter': {'gravity': 'pm' | 'p3m'}}` (Different_Sizes/Giant.param:66-68, TheFeedingPipeline/NN.param:85-87):
+ *   NB_SOLVER_PM : CIC deposit -> FFT -> -4 pi G / k^2, CIC deconvolved twice, i k differentiation -> CIC interpolation
+ *   NB_SOLVER_P3M: the same mesh force damped by exp(-k^2 r_s^2), r_s = scale_cells * boxsize / ngrid, plus the
+ *                  erfc-complement pair force inside range_scales * r_s from cell lists (CONCEPT's documented defaults:
+ *                  scale_cells = 1.25, range_scales = 4.5; potential_options of NN.param:53-82: gridsize = cbrt(N),
+ *                  'Fourier' differentiation, CIC, deconvolve (True, True), interlace (True, True))
+ * Two interlaced lattices unless NB_MESH_NO_INTERLACE. Positions are wrapped into [0, boxsize) after every drift. */
+int nb_set_mesh(nb_ctx* ctx, int solver, double boxsize, int ngrid, double scale_cells, double range_scales, int flags);
 /* one generalised KDK step: v += a*kick1; x += v*drift; a = a(x); v += a*kick2 — with kick = integral dt/a and
  * drift = integral dt/a^2 this is the comoving leapfrog of a cosmological run (v = canonical momentum per unit mass) */
 int nb_kdk_step(nb_ctx* ctx, double kick1, double drift, double kick2, double eps, double G);

@@ -1,0 +1,138 @@
+"""PM / P3M on the GPU (csrc/mesh.hip, through nb_set_mesh + nb_accel) against the NumPy oracle, part by part, and against the
+Ewald solver (the physics check: P3M -> exact periodic gravity)."""
+import numpy as np
+import pytest
+
+import bachelor_thesis_n_body_amd as nb
+from oracle import ewald_oracle as eo
+from oracle import mesh_oracle as mo
+
+pytestmark = pytest.mark.gpu
+DTYPES = [np.float32, np.float64]
+
+
+def _accel(pos, m, dtype, L, solver, ngrid, eps=0.0, G=1.0, **kw):
+    s = nb.State(pos.astype(dtype), np.zeros_like(pos, dtype=dtype), m.astype(dtype))
+    with nb.Engine(s.n, dtype) as e:
+        e.set_mesh(solver, L, ngrid, **kw)
+        e.set_state(s)
+        return e.accel(eps, G).astype(np.float64)
+
+
+def _cloud(n, L, seed=0, clustered=False):
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(0, L, (n, 3))
+    if clustered:                     # two thirds of the particles in one tight blob: many empty cells, one very full one
+        k = 2 * n // 3
+        pos[:k] = np.mod(0.5 * L + 0.03 * L * rng.normal(size=(k, 3)), L)
+    return pos, rng.uniform(0.5, 1.5, n)
+
+
+def _scale(a):
+    return np.sqrt((a * a).sum(1).mean())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ngrid,interlace", [(16, True), (32, True), (32, False), (27, True)])
+def test_pm_matches_oracle(dtype, ngrid, interlace):
+    L = 50.0
+    pos, m = _cloud(3001, L, 1)
+    got = _accel(pos, m, dtype, L, "pm", ngrid, G=2.0, interlace=interlace)
+    p = pos.astype(dtype).astype(np.float64); mm = m.astype(dtype).astype(np.float64)
+    ref = mo.mesh_accel(p, mm, L, ngrid, 2.0, None, interlace)
+    assert np.abs(got - ref).max() < (1e-10 if dtype == np.float64 else 3e-6) * _scale(ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("clustered", [False, True])
+def test_p3m_parts_match_oracle(dtype, clustered):
+    L, ngrid, eps = 80.0, 32, 0.2
+    pos, m = _cloud(4000, L, 2, clustered)
+    p = pos.astype(dtype).astype(np.float64); mm = m.astype(dtype).astype(np.float64)
+    rs = 1.25 * L / ngrid
+    ref_l = mo.mesh_accel(p, mm, L, ngrid, 1.0, rs, True)
+    ref_s = mo.short_range_accel(p, mm, L, rs, 4.5 * rs, eps)
+    got_l = _accel(pos, m, dtype, L, "p3m", ngrid, eps, part="long")
+    got_s = _accel(pos, m, dtype, L, "p3m", ngrid, eps, part="short")
+    got = _accel(pos, m, dtype, L, "p3m", ngrid, eps)
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    assert np.abs(got_l - ref_l).max() < tol * _scale(ref_l)
+    assert np.abs(got_s - ref_s).max() < tol * _scale(ref_s)
+    assert np.abs(got - (ref_l + ref_s)).max() < tol * _scale(ref_s)
+
+
+def test_p3m_agrees_with_ewald_solver():
+    """The two periodic solvers of the library against each other and against the Ewald oracle."""
+    L, n, eps = 100.0, 6000, 0.3
+    pos, m = _cloud(n, L, 3)
+    s = nb.State(pos, np.zeros_like(pos), m)
+    with nb.Engine(n, np.float64) as e:
+        e.set_periodic(L)
+        e.set_state(s)
+        ew = e.accel(eps)
+    p3 = _accel(pos, m, np.float64, L, "p3m", 32, eps)
+    err = np.linalg.norm(p3 - ew, axis=1) / np.linalg.norm(ew, axis=1)
+    assert np.sqrt((err ** 2).mean()) < 6e-3
+    sub = slice(0, 300)
+    ref = eo.ewald_accel(pos, m, L, eps)[sub]
+    err = np.linalg.norm(p3[sub] - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert np.sqrt((err ** 2).mean()) < 6e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_positions_outside_the_box_and_on_cell_edges(dtype):
+    L, ngrid = 40.0, 24
+    pos, m = _cloud(1000, L, 4)
+    pos[:50] = np.floor(pos[:50] / (L / ngrid)) * (L / ngrid)          # exactly on mesh nodes
+    pos[50] = [0.0, 0.0, 0.0]; pos[51] = [L, L, L]; pos[52] = [L - 1e-9, 0.0, L / 2]
+    shifted = pos + np.array([L, -L, 2 * L]) * (np.arange(1000) % 2)[:, None]
+    a0 = _accel(pos, m, dtype, L, "p3m", ngrid, 0.1)
+    a1 = _accel(shifted, m, dtype, L, "p3m", ngrid, 0.1)
+    assert np.isfinite(a0).all()
+    tol = 1e-9 if dtype == np.float64 else 2e-4       # fp32: the shifted coordinates themselves lose 3 digits
+    assert np.abs(a1 - a0).max() < tol * _scale(a0)
+
+
+def test_momentum_is_conserved_by_both_parts():
+    L = 60.0
+    pos, m = _cloud(5000, L, 5, clustered=True)
+    for part in ("long", "short", "both"):
+        a = _accel(pos, m, np.float64, L, "p3m", 32, 0.2, part=part)
+        assert np.abs((m[:, None] * a).sum(0)).max() < 1e-9 * np.abs(m[:, None] * a).sum()
+
+
+def test_mesh_argument_errors():
+    s = nb.plummer_sphere(256, 1, np.float32)
+    with nb.Engine(s.n, np.float32) as e:
+        with pytest.raises(RuntimeError, match="boxsize"):
+            e.set_mesh("pm", 0.0, 16)
+        with pytest.raises(RuntimeError, match="grid size"):
+            e.set_mesh("pm", 1.0, 2)
+        with pytest.raises(RuntimeError, match="too coarse"):
+            e.set_mesh("p3m", 1.0, 16)             # cut-off 5.6 cells: fewer than 3 short-range cells per side
+        e.set_mesh("pm", 1.0, 16)                  # fine for PM
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_steps_wrap_positions_and_track_the_ewald_trajectory(dtype):
+    L, n = 30.0, 2000
+    pos, m = _cloud(n, L, 6)
+    rng = np.random.default_rng(7)
+    vel = rng.normal(size=(n, 3))
+    s = nb.State(pos.astype(dtype), vel.astype(dtype), m.astype(dtype))
+    out = {}
+    for name in ("p3m", "ewald"):
+        with nb.Engine(n, dtype) as e:
+            if name == "p3m":
+                e.set_mesh("p3m", L, 32)
+            else:
+                e.set_periodic(L)
+            e.set_state(s)
+            e.step(0.05, 20, 0.1)
+            out[name] = e.get_state()
+    assert out["p3m"].pos.min() >= 0.0 and out["p3m"].pos.max() <= L
+    wrap = lambda d: d - L * np.rint(d / L)
+    d = wrap(out["p3m"].pos.astype(np.float64) - out["ewald"].pos.astype(np.float64))
+    by_force = wrap(out["ewald"].pos.astype(np.float64) - (pos + vel * (0.05 * 20)))      # what gravity did to the orbits
+    rms = lambda a: np.sqrt((a * a).sum(1).mean())
+    assert rms(d) < 0.05 * rms(by_force)          # same trajectories up to the sub-percent force error of the mesh
