@@ -8,10 +8,11 @@ reads nothing from it but the exit status, and later opens `<output_dirs['snapsh
 (`params.py`) and leaves the same artefacts behind, so a farm script can point `concept` at
 `python -m bachelor_thesis_n_body_amd.concept`.
 
-SCOPE — what it is NOT: CONCEPT integrates comoving coordinates in an expanding background with periodic (Ewald)
-forces and LPT velocities; this engine integrates the ISOLATED NEWTONIAN problem. Only
-`select_forces = {'matter': {'gravity': 'pp'}}` is accepted; the scale factors in `output_times` are used as file labels,
-the run length is `--steps` fixed KDK steps of `--dt` Gyr. Initial conditions: a CONCEPT snapshot (`--ic`, or
+Two modes. Default: the ISOLATED NEWTONIAN problem of SURVEY.md §0 item 2 (only `'gravity': 'pp'`; the scale factors in
+`output_times` are file labels, the run length is `--steps` fixed KDK steps of `--dt` Gyr). With `--cosmological`: what
+CONCEPT itself integrates — comoving coordinates in an expanding flat LCDM background, periodic box, Zel'dovich initial
+conditions at `a_begin` — with `'gravity': 'pp'` (Ewald summation), `'pm'` or `'p3m'` (mesh size, interlacing and
+short-range parameters from `potential_options` / `shortrange_params`, `params.mesh_options`). Initial conditions: a CONCEPT snapshot (`--ic`, or
 `initial_conditions = '<path>'`), or a Zel'dovich-displaced lattice of N = n^3 particles at rest from a tabulated P(k)
 (`--pk-table`, two columns k [1/Mpc], P [Mpc^3]) seeded by `random_seeds`.
 """
@@ -58,7 +59,10 @@ def _run_cosmological(args, p, s) -> int:
     total = np.log(outs[-1] / a0)
     for a1 in outs:
         k = max(1, round(nsteps * np.log(a1 / a0) / total))
-        pos, vel = cosmo.run_pp(pos, vel, mass, L, c, a0, a1, nsteps=k, eps=args.eps)
+        pos, vel = cosmo.run_pp(pos, vel, mass, L, c, a0, a1, nsteps=k, eps=args.eps, gravity=s["gravity"],
+                                dtype=np.float32 if args.dtype == "f32" else np.float64,
+                                ngrid=s["mesh"]["gridsize"], interlace=s["mesh"]["interlace"],
+                                scale_cells=s["mesh"]["scale"], range_scales=s["mesh"]["range"])
         snapshot.write_snapshot(str(out / f"snapshot_a={a1:.2f}.hdf5"), pos, vel * mass, L, mass=mass,
                                 extra_attrs={"a": float(a1), "H0": float(p["H0"])})
         if s["powerspec_dir"]:
@@ -66,7 +70,7 @@ def _run_cosmological(args, p, s) -> int:
             kk, pk, cnt = field.power_spectrum(pos, L, n_side, deconvolve=True)
             _write_powerspec(pdir / f"powerspec_a={a1:.2f}", kk, pk, cnt, a1, n_side)
         a0 = a1
-    print(f"concept: cosmological pp run finished at a = {a0:g}; {len(outs)} snapshot(s) in {out}")
+    print(f"concept: cosmological {s['gravity']} run finished at a = {a0:g}; {len(outs)} snapshot(s) in {out}")
     return 0
 
 
@@ -97,10 +101,16 @@ def main(argv=None) -> int:
     except _params.ParamError as e:
         print(f"concept: {e}", file=sys.stderr)
         return 2
-    if s["gravity"] != "pp":
-        print(f"concept: select_forces gravity = {s['gravity']!r}: this engine implements direct summation ('pp') only",
-              file=sys.stderr)
+    if s["gravity"] not in ("pp", "pm", "p3m"):
+        print(f"concept: select_forces gravity = {s['gravity']!r}: this engine implements 'pp', 'pm' and 'p3m'", file=sys.stderr)
         return 3
+    if s["gravity"] != "pp" and not args.cosmological:
+        print(f"concept: 'gravity': {s['gravity']!r} is a periodic-box solver: run it with --cosmological "
+              "(the isolated Newtonian mode implements 'pp' only)", file=sys.stderr)
+        return 3
+    if s["gravity"] != "pp" and s["mesh"]["differentiation"] != "Fourier":
+        print(f"concept: note: potential differentiation {s['mesh']['differentiation']!r} requested; this engine differentiates "
+              "in Fourier space", file=sys.stderr)
     if not s["snapshot_dir"]:
         print("concept: output_dirs['snapshot'] missing", file=sys.stderr)
         return 2

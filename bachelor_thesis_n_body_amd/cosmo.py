@@ -103,17 +103,28 @@ def zeldovich_ics(pk_table, n_side: int, boxsize: float, cosmo: Cosmology, a_beg
 
 def run_pp(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: float, a_end: float = 1.0, nsteps: int = 400,
            eps: Optional[float] = None, alpha_L: float = 6.2, kmax: int = 7,
-           callback: Optional[Callable[[float, "object"], None]] = None, device: int = 0, dtype=np.float64):
-    """Comoving periodic `pp` run on the GPU with `nsteps` steps uniform in ln a. Returns (pos, vel) at a_end.
-    dtype float32 selects the fp32 Ewald kernel (~5x faster, forces good to ~1e-5)."""
+           callback: Optional[Callable[[float, "object"], None]] = None, device: int = 0, dtype=np.float64,
+           gravity: str = "pp", ngrid: Optional[int] = None, interlace: bool = True, scale_cells: float = 1.25,
+           range_scales: float = 4.5):
+    """Comoving periodic run on the GPU with `nsteps` steps uniform in ln a. Returns (pos, vel) at a_end.
+    gravity = 'pp' (Ewald summation; dtype float32 selects the fp32 kernel, ~5x faster, forces good to ~1e-5),
+    'pm' or 'p3m' (mesh of ngrid^3 cells, default cbrt(N) / 2 cbrt(N) as in CONCEPT) — the three solvers of
+    PPPMP3M/pppmp3mplotter.py:14."""
     from .api import Engine
     from .state import State
     n = pos.shape[0]
     if eps is None:
         eps = 0.03 * boxsize / round(n ** (1.0 / 3.0))
     edges = np.exp(np.linspace(np.log(a_begin), np.log(a_end), nsteps + 1))
+    if gravity not in ("pp", "pm", "p3m"):
+        raise ValueError("gravity must be 'pp', 'pm' or 'p3m'")
     with Engine(n, dtype, device) as e:
-        e.set_periodic(boxsize, alpha_L, kmax)
+        if gravity == "pp":
+            e.set_periodic(boxsize, alpha_L, kmax)
+        else:
+            cb = round(n ** (1.0 / 3.0))
+            e.set_mesh(gravity, boxsize, int(ngrid) if ngrid else (cb if gravity == "pm" else 2 * cb), scale_cells, range_scales,
+                       interlace)
         e.set_state(State(np.asarray(pos, dtype), np.asarray(vel, dtype), np.full(n, mass, dtype)))
         for a0, a1 in zip(edges[:-1], edges[1:]):
             am = np.sqrt(a0 * a1)
@@ -122,6 +133,9 @@ def run_pp(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: flo
                 callback(float(a1), e)
         st = e.get_state()
     return st.pos.astype(np.float64), st.vel.astype(np.float64)
+
+
+run_nbody = run_pp          # the name that fits all three solvers
 
 
 def power_modes(pos, boxsize: float, ngrid: int, interlace: bool = True):

@@ -86,6 +86,64 @@ def parse(path, overrides: Dict[str, Any] | None = None) -> Dict[str, Any]:
     return out
 
 
+def _gridsize_value(v, n: int) -> int:
+    """An entry of `potential_options['gridsize']`: a number, or an expression in N such as 'cbrt(N)' / '2*cbrt(N)'
+    (Different_Sizes/Giant.param:33-36); pairs (upstream, downstream) are given as 2-sequences."""
+    if isinstance(v, (list, tuple)):
+        v = v[0]
+    if isinstance(v, (set, frozenset)):                      # Giant.param:31 writes {'global': {_size}}
+        v = next(iter(v))
+    if isinstance(v, str):
+        cb = round(n ** (1.0 / 3.0))
+        v = eval(v.replace("Ñ", "N"), {"__builtins__": {}}, {"N": n, "cbrt": lambda x: round(x ** (1.0 / 3.0)), "cbrtN": cb})
+    return int(round(float(v)))
+
+
+def mesh_options(p: Dict[str, Any], gravity, n: int) -> Dict[str, Any]:
+    """`potential_options` reduced to what the PM / P3M solvers use (TheFeedingPipeline/NN.param:53-82,
+    Different_Sizes/Giant.param:28-63): mesh size, interlacing, and the P3M short-range scale / range in CONCEPT's
+    `shortrange_params` convention. Unspecified values take CONCEPT's documented defaults: gridsize cbrt(N) for pm and
+    2 cbrt(N) for p3m, no interlacing, scale 1.25 cells, range 4.5 scales. Differentiation is always done in Fourier space
+    (the choice NN.param:55-61 makes); a finite-difference order in the file is accepted and noted by the CLI."""
+    out = {"gridsize": None, "interlace": False, "scale": 1.25, "range": 4.5, "differentiation": "Fourier"}
+    if gravity not in ("pm", "p3m") or n <= 0:
+        return out
+    cb = round(n ** (1.0 / 3.0))
+    out["gridsize"] = cb if gravity == "pm" else 2 * cb
+    po = p.get("potential_options", {})
+    if isinstance(po, dict):
+        g = po.get("gridsize")
+        if isinstance(g, dict):
+            sub = g.get("particles", {})
+            sub = sub.get("gravity", {}) if isinstance(sub, dict) else {}
+            if isinstance(sub, dict) and gravity in sub:
+                out["gridsize"] = _gridsize_value(sub[gravity], n)
+            elif g.get("global"):
+                out["gridsize"] = _gridsize_value(g["global"], n)
+        elif g is not None:
+            out["gridsize"] = _gridsize_value(g, n)
+        il = po.get("interlace")
+        if isinstance(il, dict):
+            il = il.get("gravity", il)
+            il = il.get(gravity, il.get("default", False)) if isinstance(il, dict) else il
+        if il is not None and not isinstance(il, dict):
+            out["interlace"] = bool(any(il)) if isinstance(il, (list, tuple)) else bool(il)
+        df = po.get("differentiation")
+        while isinstance(df, dict):
+            df = df.get(gravity, df.get("gravity", df.get("all", df.get("default", next(iter(df.values()), None)))))
+        if df is not None:
+            out["differentiation"] = df
+    sr = p.get("shortrange_params", {})
+    if isinstance(sr, dict):
+        sr = sr.get("gravity", sr)
+        if isinstance(sr, dict):
+            for key in ("scale", "range"):
+                v = sr.get(key)
+                if isinstance(v, (int, float)):
+                    out[key] = float(v)
+    return out
+
+
 def settings(p: Dict[str, Any]) -> Dict[str, Any]:
     """The keys the engine acts on, validated (SURVEY.md §8f-4 list)."""
     ic = p.get("initial_conditions")
@@ -103,6 +161,7 @@ def settings(p: Dict[str, Any]) -> Dict[str, Any]:
     for comp, d in forces.items():
         if isinstance(d, dict) and "gravity" in d:
             gravity = d["gravity"]
+    mesh = mesh_options(p, gravity, n)
     out_dirs = p.get("output_dirs", {})
     times = p.get("output_times", {})
     snap_times = times.get("snapshot", times.get("a", {}).get("snapshot", [])) if isinstance(times, dict) else []
@@ -114,7 +173,7 @@ def settings(p: Dict[str, Any]) -> Dict[str, Any]:
         "snapshot_dir": out_dirs.get("snapshot"), "powerspec_dir": out_dirs.get("powerspec"),
         "snapshot_times": [float(t) for t in snap_times],
         "powerspec_times": [float(t) for t in (times.get("powerspec", []) if isinstance(times, dict) else [])],
-        "gravity": gravity,
+        "gravity": gravity, "mesh": mesh,
         "random_seeds": dict(p.get("random_seeds", {})),
         "primordial_spectrum": dict(p.get("primordial_spectrum", {})),
         "a_begin": float(p.get("a_begin", 1.0)),

@@ -48,3 +48,30 @@ def test_cli_cosmological_run(tmp_path):
     q = np.array(np.meshgrid(g, g, g, indexing="ij")).reshape(3, -1).T
     disp = lambda x: np.abs((x - q + 250.0) % 500.0 - 250.0).mean()
     assert disp(late) > 3 * disp(early)
+
+
+def test_cli_cosmological_p3m_and_pm_follow_the_pp_run(tmp_path):
+    """`'gravity': 'p3m'` / `'pm'` with `potential_options` from the parameter file: same realisation, same physics as the
+    Ewald `pp` run up to the mesh force error (p3m) / the missing sub-mesh forces (pm)."""
+    k = np.logspace(-3, 1, 200)
+    np.savetxt(tmp_path / "pk.txt", np.column_stack([k, 2.0e4 * (k / 0.02) / (1 + (k / 0.02) ** 2) ** 1.6]))
+    late = {}
+    for grav in ("pp", "p3m", "pm"):
+        d = tmp_path / grav
+        d.mkdir()
+        f = _write(d, grav)
+        rc = concept.main(["-p", str(f), "-n", "1", "--local", "--cosmological", "--pk-table", str(tmp_path / "pk.txt"), "--steps", "40",
+                           "-c", "potential_options = {'gridsize': 24, 'interlace': {'gravity': {'pm': (True, True), 'p3m': (True, True)}}}"])
+        assert rc == 0
+        late[grav] = sn.read_positions(str(next((d / "output").rglob("snapshot_a=1.00.hdf5"))))
+    g = np.linspace(0, 500.0, 8, endpoint=False)
+    q = np.array(np.meshgrid(g, g, g, indexing="ij")).reshape(3, -1).T
+    wrap = lambda x: (x + 250.0) % 500.0 - 250.0
+    rms = lambda x: np.sqrt((x * x).sum(1).mean())
+    moved = rms(wrap(late["pp"] - q))
+    assert rms(wrap(late["p3m"] - late["pp"])) < 0.08 * moved          # 8^3 particles ON the vertices of a 24^3 mesh: worst case for CIC
+    assert rms(wrap(late["pm"] - late["pp"])) < 0.5 * moved
+    # a mesh too coarse for the P3M cut-off is an error the CLI reports, not a crash
+    f = _write(tmp_path, "p3m")
+    with pytest.raises(RuntimeError, match="too coarse"):
+        concept.main(["-p", str(f), "--cosmological", "--pk-table", str(tmp_path / "pk.txt"), "--steps", "2"])

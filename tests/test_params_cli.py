@@ -79,7 +79,9 @@ def test_errors(tmp_path):
 
 def test_cli_rejects_other_solvers_and_missing_inputs(tmp_path, capsys):
     assert concept.main(["-p", str(_write(tmp_path, "p3m")), "-n", "1", "--local"]) == 3
-    assert "direct summation ('pp') only" in capsys.readouterr().err
+    assert "--cosmological" in capsys.readouterr().err                 # mesh solvers are periodic-box solvers
+    assert concept.main(["-p", str(_write(tmp_path, "tree")), "-n", "1", "--local"]) == 3
+    assert "implements 'pp', 'pm' and 'p3m'" in capsys.readouterr().err
     assert concept.main(["-p", str(tmp_path / "nope.param")]) != 0 if (tmp_path / "nope.param").exists() else True
     bad = tmp_path / "bad.param"
     bad.write_text("x = = 1\n")
@@ -93,3 +95,18 @@ def test_reference_param_files_parse():
     n = params.settings(params.parse(REF / "TheFeedingPipeline" / "NN.param"))
     assert n["N"] == 32 ** 3 and n["boxsize"] == 500.0 and n["gravity"] == "p3m"
     assert n["snapshot_dir"].endswith("NNPM32_As2.11e-09/snapshots")      # the directory name seen in Datafolder4
+    # potential_options -> mesh settings (NN.param:53-82: gridsize _size, interlace (True, True), Fourier differentiation)
+    assert n["mesh"] == {"gridsize": 32, "interlace": True, "scale": 1.25, "range": 4.5, "differentiation": "Fourier"}
+    assert g["mesh"]["gridsize"] == 256 and g["mesh"]["interlace"] is True          # Giant.param:29-51: 'cbrt(N)' pairs
+
+
+def test_mesh_option_defaults_and_forms():
+    n = 16 ** 3
+    assert params.mesh_options({}, "pp", n)["gridsize"] is None
+    assert params.mesh_options({}, "pm", n)["gridsize"] == 16 and params.mesh_options({}, "p3m", n)["gridsize"] == 32
+    assert params.mesh_options({}, "p3m", n)["interlace"] is False
+    po = {"gridsize": {"particles": {"gravity": {"p3m": ("2*cbrt(N)", "cbrt(N)")}}}, "interlace": {"gravity": {"p3m": (True, False)}},
+          "differentiation": {"default": {"gravity": {"p3m": 4}}}}
+    m = params.mesh_options({"potential_options": po, "shortrange_params": {"gravity": {"scale": 1.0, "range": 5.0}}}, "p3m", n)
+    assert m == {"gridsize": 32, "interlace": True, "scale": 1.0, "range": 5.0, "differentiation": 4}
+    assert params.mesh_options({"potential_options": {"gridsize": 24}}, "pm", n)["gridsize"] == 24
