@@ -19,10 +19,11 @@
 //              (g_x, g_y, g_z on both lattices) are packed pairwise into three complex grids      [HBM bound, 16 B in, 48 B out per mode]
 //   inverse    3 x hipFFT Z2Z backward
 //   gather     CIC interpolation of both lattices to the particles, averaged                         [HBM gather bound]
-// Short range: particles are counting-sorted (rocPRIM radix sort) into cells of side >= r_cut; one 128-thread block
-// per (cell, 128-sink chunk) walks the 27 neighbour cells, source tiles staged through LDS and read back as
-// wave-uniform broadcasts (the accel_f32.hip pattern); the periodic image is a per-neighbour-cell shift, not a
-// per-pair minimum image.                                                                           [VALU bound]
+// Short range: particles are sorted (rocPRIM radix sort) by cell of side >= r_cut, then by Morton sub-cell; one 128-thread
+// block per chunk of 128 consecutive particles of a row of cells walks the neighbouring rows, source tiles staged through
+// LDS and read back as wave-uniform broadcasts (the accel_f32.hip pattern); a wave-level vote skips the erfc/exp
+// arithmetic for sources out of reach of all 64 sinks; the periodic image is a per-segment shift, not a per-pair
+// minimum image.                                                                                    [VALU bound]
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
 #include <cstring>
@@ -49,6 +50,7 @@ struct nb_mesh_state {
 namespace {
 
 constexpr int SRB = 128;   // short-range block = sink chunk = source tile
+constexpr int SUBBITS = 6; // sub-cell bits below the cell index in the sort key
 
 struct d4 { double x, y, z, w; };
 
@@ -184,7 +186,11 @@ cell_key_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __res
   px -= L * floor(px * invL); py -= L * floor(py * invL); pz -= L * floor(pz * invL);
   const double s = nc * invL;
   const int cx = min(nc - 1, max(0, (int)(px * s))), cy = min(nc - 1, max(0, (int)(py * s))), cz = min(nc - 1, max(0, (int)(pz * s)));
-  keys[p] = (uint32_t)((cx * nc + cy) * nc + cz);
+  // 6 low bits: Morton index of the particle's 4x4x4 sub-cell, so that 64 consecutive sorted particles (= the sinks of one
+  // wave) form a compact blob and the wave-level cut-off vote of the pair loop can skip most sources
+  const int sx = min(3, max(0, (int)((px * s - cx) * 4.0))), sy = min(3, max(0, (int)((py * s - cy) * 4.0))), sz = min(3, max(0, (int)((pz * s - cz) * 4.0)));
+  const uint32_t sub = (uint32_t)(((sx >> 1) << 5) | ((sy >> 1) << 4) | ((sz >> 1) << 3) | ((sx & 1) << 2) | ((sy & 1) << 1) | (sz & 1));
+  keys[p] = ((uint32_t)((cx * nc + cy) * nc + cz) << SUBBITS) | sub;
   idx[p] = (uint32_t)p;
 }
 
@@ -207,16 +213,16 @@ __global__ void __launch_bounds__(256)
 cell_start_kernel(const uint32_t* __restrict__ keys_s, int64_t n, int ncell3, int* __restrict__ cell_start) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p > n) return;
-  const int lo = p == 0 ? 0 : (int)keys_s[p - 1] + 1;
-  const int hi = p == n ? ncell3 : (int)keys_s[p];
+  const int lo = p == 0 ? 0 : (int)(keys_s[p - 1] >> SUBBITS) + 1;
+  const int hi = p == n ? ncell3 : (int)(keys_s[p] >> SUBBITS);
   for (int c = lo; c <= hi; ++c) cell_start[c] = (int)p;
 }
 
 __global__ void __launch_bounds__(256)
-chunk_count_kernel(const int* __restrict__ cell_start, int ncell3, int* __restrict__ cnt) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c > ncell3) return;
-  cnt[c] = c < ncell3 ? (cell_start[c + 1] - cell_start[c] + SRB - 1) / SRB : 0;
+chunk_count_kernel(const int* __restrict__ cell_start, int nrows, int nc, int* __restrict__ cnt) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nrows) return;
+  cnt[r] = r < nrows ? (cell_start[(r + 1) * nc] - cell_start[r * nc] + SRB - 1) / SRB : 0;
 }
 
 // erfc-split pair factor:  (r^2+eps^2)^{-3/2} - (erf(a r) - 2 a r/sqrt(pi) e^{-a^2 r^2}) / r^3
@@ -242,56 +248,70 @@ __device__ inline double sr_factor(double r2, double eps2, double alpha, double 
   return soft - lng;
 }
 
+// One block per chunk of <= SRB consecutive sorted particles of one ROW of cells (fixed cx, cy; cells consecutive in z are
+// consecutive in memory). Sparse cells are packed together into full blocks; a dense cell is split into several chunks.
+// The sinks span cells lo..hi of the row; sources are the unwrapped cells lo-1..hi+1 of the 9 neighbouring rows, walked as
+// contiguous memory segments (split where the periodic image changes). Images out of reach contribute nothing through the
+// cut-off test, so every sink sees each of its 27 neighbour-cell images exactly once.
 template <typename T, typename V4>
 __global__ void __launch_bounds__(SRB)
-short_range_kernel(const V4* __restrict__ sorted, const int* __restrict__ cell_start, const int* __restrict__ chunk_off,
-                   int ncell3, int nc, T L, T alpha, T rcut2, T eps2, double G, const uint32_t* __restrict__ idx_s,
-                   T* __restrict__ ax, T* __restrict__ ay, T* __restrict__ az) {
+short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ keys_s, const int* __restrict__ cell_start,
+                   const int* __restrict__ chunk_off, int nrows, int nc, T L, T alpha, T rcut2, T eps2, double G,
+                   const uint32_t* __restrict__ idx_s, T* __restrict__ ax, T* __restrict__ ay, T* __restrict__ az) {
   __shared__ V4 tile[SRB];
-  const int total = chunk_off[ncell3];
+  const int total = chunk_off[nrows];
   const int w = blockIdx.x;
   if (w >= total) return;                       // the grid is an upper bound on the number of chunks
-  // cell = last c with chunk_off[c] <= w  (block-uniform binary search)
-  int lo = 0, hi = ncell3;
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= w) lo = mid; else hi = mid; }
-  const int cell = lo, chunk = w - chunk_off[cell];
-  const int cz = cell % nc, cy = (cell / nc) % nc, cx = cell / (nc * nc);
-  const int s0 = cell_start[cell], s1 = cell_start[cell + 1];
-  const int i = s0 + chunk * SRB + (int)threadIdx.x;
-  const bool live = i < s1;
-  const V4 me = sorted[live ? i : s1 - 1];
+  // row = last r with chunk_off[r] <= w  (block-uniform binary search)
+  int lo_r = 0, hi_r = nrows;
+  while (hi_r - lo_r > 1) { const int mid = (lo_r + hi_r) >> 1; if (chunk_off[mid] <= w) lo_r = mid; else hi_r = mid; }
+  const int row = lo_r, chunk = w - chunk_off[row];
+  const int cx = row / nc, cy = row % nc;
+  const int r1 = cell_start[(row + 1) * nc];
+  const int i_first = cell_start[row * nc] + chunk * SRB, i_last = min(r1, i_first + SRB) - 1;
+  const int zlo = (int)((keys_s[i_first] >> SUBBITS) % (uint32_t)nc), zhi = (int)((keys_s[i_last] >> SUBBITS) % (uint32_t)nc);
+  const int i = i_first + (int)threadIdx.x;
+  const bool live = i <= i_last;
+  const V4 me = sorted[live ? i : i_last];
   const T c2 = (T)2 * alpha * (T)0.5641895835477563, a2l = -alpha * alpha * (T)1.4426950408889634;
   double tx = 0.0, ty = 0.0, tz = 0.0;
-  for (int nb = 0; nb < 27; ++nb) {
-    const int ox = nb / 9 - 1, oy = (nb / 3) % 3 - 1, oz = nb % 3 - 1;
-    int qx = cx + ox, qy = cy + oy, qz = cz + oz;
-    T shx = 0, shy = 0, shz = 0;                // periodic image of the whole neighbour cell
+  for (int nb = 0; nb < 9; ++nb) {
+    int qx = cx + nb / 3 - 1, qy = cy + nb % 3 - 1;
+    T shx = 0, shy = 0;                         // periodic image of the whole neighbour row
     if (qx < 0) { qx += nc; shx = -L; } else if (qx >= nc) { qx -= nc; shx = L; }
     if (qy < 0) { qy += nc; shy = -L; } else if (qy >= nc) { qy -= nc; shy = L; }
-    if (qz < 0) { qz += nc; shz = -L; } else if (qz >= nc) { qz -= nc; shz = L; }
-    const int q = (qx * nc + qy) * nc + qz;
-    const int b0 = cell_start[q], b1 = cell_start[q + 1];
-    for (int j0 = b0; j0 < b1; j0 += SRB) {
-      __syncthreads();
-      const int j = j0 + (int)threadIdx.x;
-      if (j < b1) {
-        V4 s = sorted[j];
-        s.x += shx; s.y += shy; s.z += shz;
-        tile[threadIdx.x] = s;
+    const int qbase = (qx * nc + qy) * nc;
+    for (int a = zlo - 1; a <= zhi + 1;) {
+      const int img = a < 0 ? -1 : a / nc;                      // which periodic image along z
+      const int b = min(zhi + 1, (img + 1) * nc - 1);           // last cell of this segment
+      const T shz = (T)img * L;
+      const int b0 = cell_start[qbase + (a - img * nc)], b1 = cell_start[qbase + (b - img * nc) + 1];
+      a = b + 1;
+      for (int j0 = b0; j0 < b1; j0 += SRB) {
+        __syncthreads();
+        const int j = j0 + (int)threadIdx.x;
+        if (j < b1) {
+          V4 s = sorted[j];
+          s.x += shx; s.y += shy; s.z += shz;
+          tile[threadIdx.x] = s;
+        }
+        __syncthreads();
+        const int cnt = min(SRB, b1 - j0);
+        T fx = 0, fy = 0, fz = 0;
+        for (int e = 0; e < cnt; ++e) {
+          const V4 s = tile[e];                   // wave-uniform address: LDS broadcast
+          const T dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
+          const T r2 = dx * dx + dy * dy + dz * dz;
+          // wave-uniform branch: the 64 sinks of a wave are a compact blob (sub-cell sort), most sources of the walked
+          // cells are out of reach of all of them and cost only the distance test
+          if (__builtin_amdgcn_ballot_w64(r2 < rcut2) != 0) {
+            T f = s.w * sr_factor(r2, eps2, alpha, c2, a2l);
+            f = r2 < rcut2 ? f : (T)0;
+            fx += f * dx; fy += f * dy; fz += f * dz;
+          }
+        }
+        tx += (double)fx; ty += (double)fy; tz += (double)fz;
       }
-      __syncthreads();
-      const int cnt = min(SRB, b1 - j0);
-      T fx = 0, fy = 0, fz = 0;
-#pragma unroll 4
-      for (int e = 0; e < cnt; ++e) {
-        const V4 s = tile[e];                   // wave-uniform address: LDS broadcast
-        const T dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
-        const T r2 = dx * dx + dy * dy + dz * dz;
-        T f = s.w * sr_factor(r2, eps2, alpha, c2, a2l);
-        f = r2 < rcut2 ? f : (T)0;
-        fx += f * dx; fy += f * dy; fz += f * dz;
-      }
-      tx += (double)fx; ty += (double)fy; tz += (double)fz;
     }
   }
   if (live) {
@@ -367,18 +387,20 @@ int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z,
   cell_key_kernel<T><<<nb, 256, 0, st>>>(x, y, z, n, L, nc, s.keys, s.idx);
   NB_HIP(c, hipGetLastError());
   int bits = 1; while ((1u << bits) < (unsigned)ncell3) ++bits;
+  bits += SUBBITS;
   size_t tb = s.tmp_bytes;
   NB_HIP(c, rocprim::radix_sort_pairs(s.tmp, tb, s.keys, s.keys_s, s.idx, s.idx_s, (size_t)n, 0, (unsigned)bits, st));
   sort_gather_kernel<T, V4><<<nb, 256, 0, st>>>(x, y, z, m, s.idx_s, n, L, (V4*)s.sorted);
   NB_HIP(c, hipGetLastError());
   cell_start_kernel<<<(int)((n + 1 + 255) / 256), 256, 0, st>>>(s.keys_s, n, ncell3, s.cell_start);
   NB_HIP(c, hipGetLastError());
-  chunk_count_kernel<<<(ncell3 + 1 + 255) / 256, 256, 0, st>>>(s.cell_start, ncell3, s.chunk_cnt);
+  const int nrows = nc * nc;
+  chunk_count_kernel<<<(nrows + 1 + 255) / 256, 256, 0, st>>>(s.cell_start, nrows, nc, s.chunk_cnt);
   NB_HIP(c, hipGetLastError());
   tb = s.tmp_bytes;
-  NB_HIP(c, rocprim::exclusive_scan(s.tmp, tb, s.chunk_cnt, s.chunk_off, 0, (size_t)ncell3 + 1, rocprim::plus<int>(), st));
-  const int64_t max_chunks = (int64_t)ncell3 + n / SRB + 1;     // sum_c ceil(n_c / SRB) <= ncell3 + n / SRB
-  short_range_kernel<T, V4><<<(unsigned)max_chunks, SRB, 0, st>>>((const V4*)s.sorted, s.cell_start, s.chunk_off, ncell3, nc,
+  NB_HIP(c, rocprim::exclusive_scan(s.tmp, tb, s.chunk_cnt, s.chunk_off, 0, (size_t)nrows + 1, rocprim::plus<int>(), st));
+  const int64_t max_chunks = (int64_t)nrows + n / SRB + 1;      // sum_r ceil(n_r / SRB) <= nrows + n / SRB
+  short_range_kernel<T, V4><<<(unsigned)max_chunks, SRB, 0, st>>>((const V4*)s.sorted, s.keys_s, s.cell_start, s.chunk_off, nrows, nc,
                                                                    (T)L, (T)alpha, (T)(rcut * rcut), (T)eps2, G, s.idx_s,
                                                                    ax, ay, az);
   NB_HIP(c, hipGetLastError());
@@ -448,7 +470,7 @@ int nb_launch_accel_mesh(nb_ctx* c, int dtype, const void* x, const void* y, con
   if (p3m && (parts & 2)) {
     const int nc = (int)floor(L / rcut);
     if (nc < 3) return nb_fail(c, NB_ERR_ARG, "p3m: the short-range cut-off exceeds a third of the box (grid too coarse); use the Ewald solver");
-    if ((double)nc * nc * nc > 2.0e9) return nb_fail(c, NB_ERR_ARG, "p3m: too many short-range cells");
+    if ((double)nc * nc * nc > 6.0e7) return nb_fail(c, NB_ERR_ARG, "p3m: too many short-range cells");
     const double alpha = 1.0 / (2.0 * rs);
     if (dtype == NB_F32)
       return short_range<float, float4>(c, s, (const float*)x, (const float*)y, (const float*)z, (const float*)m, n, L, nc, alpha,
