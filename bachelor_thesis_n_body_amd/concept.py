@@ -36,6 +36,14 @@ def _write_powerspec(path: Path, k, pk, counts, a: float, ngrid: int) -> None:
             fh.write(f"{ki:.7e} {int(ci):6d}  {pi:.7e}\n")
 
 
+def _load_pk_table(args, s) -> np.ndarray:
+    tab = np.loadtxt(args.pk_table)[:, :2].astype(np.float64)
+    a_s = s["primordial_spectrum"].get("A_s")
+    if args.pk_table_As is not None and a_s is not None:
+        tab[:, 1] *= float(a_s) / float(args.pk_table_As)
+    return tab
+
+
 def _run_cosmological(args, p, s) -> int:
     """CONCEPT-like run: Zel'dovich ICs at a_begin from the linear P(k) table (at a = 1), comoving KDK with periodic Ewald
     forces up to the last requested scale factor, snapshot (+ power spectrum) at every requested output time."""
@@ -49,7 +57,7 @@ def _run_cosmological(args, p, s) -> int:
     c = cosmo.Cosmology(float(p["H0"]), float(p["Ωb"]) + float(p["Ωcdm"]), (2.473e-5 * (1.0 + 0.2271 * 3.046)) / h ** 2)
     seeds = s["random_seeds"]
     a0 = s["a_begin"]
-    pos, vel = cosmo.zeldovich_ics(np.loadtxt(args.pk_table), n_side, L, c, a0, int(seeds.get("primordial amplitudes", 0)),
+    pos, vel = cosmo.zeldovich_ics(_load_pk_table(args, s), n_side, L, c, a0, int(seeds.get("primordial amplitudes", 0)),
                                    int(seeds.get("primordial phases", 1)))
     mass = c.particle_mass(L, n_side ** 3)
     outs = sorted(set(t for t in (s["snapshot_times"] or [1.0]) if t > a0))
@@ -82,6 +90,10 @@ def main(argv=None) -> int:
     ap.add_argument("-c", "--command-line-param", action="append", default=[], help="extra `name = value` lines")
     ap.add_argument("--ic", help="CONCEPT-layout snapshot to start from")
     ap.add_argument("--pk-table", help="two-column text file k [1/Mpc], P(k) [Mpc^3] for generated initial conditions")
+    ap.add_argument("--pk-table-As", type=float, default=None,
+                    help="primordial amplitude A_s the --pk-table was computed for: the table is rescaled by "
+                         "primordial_spectrum['A_s'] / this value (linear P(k) is proportional to A_s), so one table serves a farm "
+                         "that sweeps A_s per job (TheFeedingPipeline/NeuNetværk_test.py:100-137)")
     ap.add_argument("--dt", type=float, default=0.01, help="KDK step in Gyr")
     ap.add_argument("--steps", type=int, default=0)
     ap.add_argument("--eps", type=float, default=None, help="Plummer softening in Mpc (default 0.03 mean separations)")
@@ -136,7 +148,7 @@ def main(argv=None) -> int:
         if not args.pk_table:
             print("concept: generated initial conditions need --pk-table (CLASS is not available to this engine)", file=sys.stderr)
             return 2
-        tab = np.loadtxt(args.pk_table)
+        tab = _load_pk_table(args, s)
         P = grf.tabulated_pk_grid(tab[:, 0], tab[:, 1], n_side, L)
         seeds = s["random_seeds"]
         c_1 = np.random.default_rng(int(seeds.get("primordial amplitudes", 0))).normal(0, 1 / np.sqrt(2), (n_side,) * 3)

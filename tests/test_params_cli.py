@@ -110,3 +110,16 @@ def test_mesh_option_defaults_and_forms():
     m = params.mesh_options({"potential_options": po, "shortrange_params": {"gravity": {"scale": 1.0, "range": 5.0}}}, "p3m", n)
     assert m == {"gridsize": 32, "interlace": True, "scale": 1.0, "range": 5.0, "differentiation": 4}
     assert params.mesh_options({"potential_options": {"gridsize": 24}}, "pm", n)["gridsize"] == 24
+
+
+def test_pk_table_is_rescaled_by_A_s(tmp_path):
+    """One linear P(k) table serves a farm that sweeps A_s per job (NeuNetværk_test.py:100-137): P is proportional to A_s."""
+    import argparse
+    k = np.logspace(-2, 0, 5)
+    np.savetxt(tmp_path / "pk.txt", np.column_stack([k, 1e3 / k, np.zeros(5)]))          # extra columns are ignored
+    s = params.settings(params.parse(_write(tmp_path)))
+    a = argparse.Namespace(pk_table=str(tmp_path / "pk.txt"), pk_table_As=None)
+    np.testing.assert_allclose(concept._load_pk_table(a, s)[:, 1], 1e3 / k)
+    a.pk_table_As = 4.21e-9
+    np.testing.assert_allclose(concept._load_pk_table(a, s)[:, 1], 0.5 * 1e3 / k)          # the file's A_s is 2.105e-9
+    assert concept._load_pk_table(a, s).shape == (5, 2)
