@@ -57,8 +57,11 @@ def _run_cosmological(args, p, s) -> int:
     c = cosmo.Cosmology(float(p["H0"]), float(p["Ωb"]) + float(p["Ωcdm"]), (2.473e-5 * (1.0 + 0.2271 * 3.046)) / h ** 2)
     seeds = s["random_seeds"]
     a0 = s["a_begin"]
+    if s["lpt"] not in (1, 2):
+        print(f"concept: realization_options['LPT'] = {s['lpt']}: orders 1 and 2 are implemented", file=sys.stderr)
+        return 3
     pos, vel = cosmo.zeldovich_ics(_load_pk_table(args, s), n_side, L, c, a0, int(seeds.get("primordial amplitudes", 0)),
-                                   int(seeds.get("primordial phases", 1)))
+                                   int(seeds.get("primordial phases", 1)), lpt=s["lpt"])
     mass = c.particle_mass(L, n_side ** 3)
     outs = sorted(set(t for t in (s["snapshot_times"] or [1.0]) if t > a0))
     out = Path(s["snapshot_dir"])

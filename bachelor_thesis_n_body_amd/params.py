@@ -174,6 +174,7 @@ def settings(p: Dict[str, Any]) -> Dict[str, Any]:
         "snapshot_times": [float(t) for t in snap_times],
         "powerspec_times": [float(t) for t in (times.get("powerspec", []) if isinstance(times, dict) else [])],
         "gravity": gravity, "mesh": mesh,
+        "lpt": int(p.get("realization_options", {}).get("LPT", 1)) if isinstance(p.get("realization_options", {}), dict) else 1,
         "random_seeds": dict(p.get("random_seeds", {})),
         "primordial_spectrum": dict(p.get("primordial_spectrum", {})),
         "a_begin": float(p.get("a_begin", 1.0)),

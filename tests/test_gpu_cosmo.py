@@ -96,3 +96,31 @@ def test_p3m_farm_job_against_the_reference_ensemble():
     assert np.all(np.abs(ratio[2:] - 0.975) < 0.04), ratio          # bins with >= 656 modes; 12 seeds: +-0.012 statistical
     assert np.all(np.abs(ratio[:2] - 0.975) < 0.15), ratio          # 56 and 308 modes
     assert np.std(ratio[2:]) < 0.02, ratio                          # no k-dependent trend: the non-linear shape agrees
+
+
+def test_second_order_ics_are_closer_to_the_nbody_evolution_than_first_order():
+    """Sign and size of the 2LPT term (`realization_options = {'LPT': 2}`, Giant.param:70-72) on a SMOOTH field (spectrum cut off
+    at a quarter of the particle Nyquist frequency, so that the N-body system follows the fluid and the comparison is not swamped
+    by lattice discreteness): particles laid down directly at a = 0.5 with 1LPT and with 2LPT from the same noise, against the P3M
+    evolution to a = 0.5 of ICs laid down at a = 0.02."""
+    pp = np.loadtxt(TABLE)
+    k_ref, p_lin = pp[:, 0], pp[:, 4]
+    tab = np.column_stack([k_ref, p_lin * np.exp(-(k_ref / 0.05) ** 2)])
+    tab = np.vstack([tab, [[0.5, 1e-30], [1.0, 1e-30]]])
+    n_side, L = 32, 500.0
+    c = cosmo.Cosmology.from_h_omegas(0.6736, 0.02237, 0.12)
+    pos, vel = cosmo.zeldovich_ics(tab, n_side, L, c, 0.02, 3, 4, lpt=2)
+    truth, vtruth = cosmo.run_pp(pos, vel, c.particle_mass(L, n_side ** 3), L, c, 0.02, 0.5, 300, gravity="p3m", ngrid=64)
+    wrap = lambda d: d - L * np.rint(d / L)
+    rms = lambda d: np.sqrt((d * d).sum(1).mean())
+    p1, v1 = cosmo.zeldovich_ics(tab, n_side, L, c, 0.5, 3, 4, lpt=1)
+    p2, v2 = cosmo.zeldovich_ics(tab, n_side, L, c, 0.5, 3, 4, lpt=2)
+    moved = rms(wrap(truth - pos))
+    assert rms(wrap(p1 - truth)) < 0.06 * moved                         # 1LPT is already a fair approximation (4 %)
+    assert rms(wrap(p2 - truth)) < 0.85 * rms(wrap(p1 - truth)) and rms(v2 - vtruth) < 0.7 * rms(v1 - vtruth)
+    # projection of what 1LPT misses onto the second-order term: 1 if sign and size are right (the rest of the residual — third
+    # order, the sub-percent P3M force error, time stepping — is uncorrelated with it)
+    d2, dv2 = wrap(p2 - p1), v2 - v1
+    alpha_x = (wrap(truth - p1) * d2).sum() / (d2 * d2).sum()
+    alpha_v = ((vtruth - v1) * dv2).sum() / (dv2 * dv2).sum()
+    assert 0.8 < alpha_x < 1.2 and 0.8 < alpha_v < 1.2, (alpha_x, alpha_v)
