@@ -27,13 +27,19 @@ import numpy as np
 from . import params as _params
 
 
-def _write_powerspec(path: Path, k, pk, counts, a: float, ngrid: int) -> None:
-    """Text table in the column order of CONCEPT's powerspec files (k, modes, P; PPPMP3M/PP/powerspec/powerspec_a=1.00:10-26)."""
+def _write_powerspec(path: Path, k, pk, counts, a: float, ngrid: int, corrected=None, linear=None) -> None:
+    """Text table in the layout of CONCEPT's powerspec files — k, modes, P, P corrected, P linear
+    (PPPMP3M/PP/powerspec/powerspec_a=1.00:1-26) — so that the thesis' loaders, which read columns (0, 2, 3, 4)
+    (PPPMP3M/pppmp3mplotter.py:123-134, SnapVsPK/Power_compare.py:625-629), open it unchanged. Unknown columns hold nan."""
+    nan = np.full(len(k), np.nan)
+    corrected = nan if corrected is None else corrected
+    linear = nan if linear is None else linear
     with open(path, "w", encoding="utf-8") as fh:
-        fh.write(f"# Power spectrum from bachelor_thesis_n_body_amd at a = {a:g}\n#\n# grid size {ngrid}\n")
-        fh.write("#  k [Mpc⁻¹]   modes     P [Mpc³]\n")
-        for ki, ci, pi in zip(k, counts, pk):
-            fh.write(f"{ki:.7e} {int(ci):6d}  {pi:.7e}\n")
+        fh.write(f"# Power spectrum from bachelor_thesis_n_body_amd at a = {a:g}\n#\n# Components:\n#   0: matter  (upstream grid size {ngrid})\n#\n")
+        fh.write(f"#                          grid size {ngrid}\n#                      component 0    (corrected)      (linear)\n")
+        fh.write("#  k [Mpc⁻¹]   modes     P [Mpc³]       P [Mpc³]       P [Mpc³]\n")
+        for ki, ci, pi, pc, pl in zip(k, counts, pk, corrected, linear):
+            fh.write(f"{ki:.7e} {int(ci):6d}  {pi:.7e}  {pc:.7e}  {pl:.7e}\n")
 
 
 def _load_pk_table(args, s) -> np.ndarray:
@@ -60,10 +66,14 @@ def _run_cosmological(args, p, s) -> int:
     if s["lpt"] not in (1, 2):
         print(f"concept: realization_options['LPT'] = {s['lpt']}: orders 1 and 2 are implemented", file=sys.stderr)
         return 3
-    pos, vel = cosmo.zeldovich_ics(_load_pk_table(args, s), n_side, L, c, a0, int(seeds.get("primordial amplitudes", 0)),
-                                   int(seeds.get("primordial phases", 1)), lpt=s["lpt"])
+    table = _load_pk_table(args, s)
+    pos, vel, noise_power = cosmo.zeldovich_ics(table, n_side, L, c, a0, int(seeds.get("primordial amplitudes", 0)),
+                                                int(seeds.get("primordial phases", 1)), lpt=s["lpt"], return_noise_power=True)
     mass = c.particle_mass(L, n_side ** 3)
-    outs = sorted(set(t for t in (s["snapshot_times"] or [1.0]) if t > a0))
+    snap_t = set(t for t in (s["snapshot_times"] or [1.0]) if t > a0)
+    # power spectra: at `output_times['powerspec']` when given (SnapVsPK/Uncertain.param:13-16), else with every snapshot
+    ps_t = set(t for t in (s["powerspec_times"] or (snap_t if s["powerspec_dir"] else [])) if t > a0)
+    outs = sorted(snap_t | ps_t)
     out = Path(s["snapshot_dir"])
     out.mkdir(parents=True, exist_ok=True)
     nsteps = args.steps if args.steps > 0 else 400
@@ -74,14 +84,15 @@ def _run_cosmological(args, p, s) -> int:
                                 dtype=np.float32 if args.dtype == "f32" else np.float64,
                                 ngrid=s["mesh"]["gridsize"], interlace=s["mesh"]["interlace"],
                                 scale_cells=s["mesh"]["scale"], range_scales=s["mesh"]["range"])
-        snapshot.write_snapshot(str(out / f"snapshot_a={a1:.2f}.hdf5"), pos, vel * mass, L, mass=mass,
-                                extra_attrs={"a": float(a1), "H0": float(p["H0"])})
-        if s["powerspec_dir"]:
-            pdir = Path(s["powerspec_dir"]); pdir.mkdir(parents=True, exist_ok=True)
-            kk, pk, cnt = field.power_spectrum(pos, L, n_side, deconvolve=True)
-            _write_powerspec(pdir / f"powerspec_a={a1:.2f}", kk, pk, cnt, a1, n_side)
+        if a1 in snap_t:
+            snapshot.write_snapshot(str(out / f"snapshot_a={a1:.2f}.hdf5"), pos, vel * mass, L, mass=mass,
+                                    extra_attrs={"a": float(a1), "H0": float(p["H0"])})
+        if a1 in ps_t:
+            pdir = Path(s["powerspec_dir"] or out.parent / "powerspec"); pdir.mkdir(parents=True, exist_ok=True)
+            kk, cnt, pk, pcorr, plin = cosmo.concept_power_table(pos, L, n_side, table, c.growth(a1)[0], noise_power)
+            _write_powerspec(pdir / f"powerspec_a={a1:.2f}", kk, pk, cnt, a1, n_side, pcorr, plin)
         a0 = a1
-    print(f"concept: cosmological {s['gravity']} run finished at a = {a0:g}; {len(outs)} snapshot(s) in {out}")
+    print(f"concept: cosmological {s['gravity']} run finished at a = {a0:g}; {len(snap_t)} snapshot(s) in {out}")
     return 0
 
 

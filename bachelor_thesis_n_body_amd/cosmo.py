@@ -105,7 +105,7 @@ def second_order_potential_gradient(psi, boxsize: float) -> np.ndarray:
 
 
 def zeldovich_ics(pk_table, n_side: int, boxsize: float, cosmo: Cosmology, a_begin: float, seed_amp: int = 0,
-                  seed_phase: int = 1, lpt: int = 1):
+                  seed_phase: int = 1, lpt: int = 1, return_noise_power: bool = False):
     """Lattice + growing-mode displacement at a_begin from the LINEAR spectrum at a = 1 (two columns k, P):
     returns comoving positions (N,3) in [0, L) and v = a^2 dx/dt (N,3). lpt = 2 adds the second-order displacement
     D2 grad(phi2) with D2 = -(3/7) D1^2 Omega_m(a)^(-1/143), f2 = 2 Omega_m(a)^(6/11)."""
@@ -120,6 +120,7 @@ def zeldovich_ics(pk_table, n_side: int, boxsize: float, cosmo: Cosmology, a_beg
         plan.set_noise(c_1, c_2, "skip_self")
         plan.set_spectrum(P)
         psi = np.stack([plan.field(c + 1).reshape(-1) for c in range(3)], axis=1)
+        noise_power = np.abs(plan.noise()) ** 2 if return_noise_power else None    # |R_k|^2: the realisation's power / expectation
     g = np.linspace(0, boxsize, n_side, endpoint=False)
     q = np.array(np.meshgrid(g, g, g, indexing="ij")).reshape(3, -1).T
     aH = a_begin ** 2 * float(cosmo.H(a_begin))
@@ -133,7 +134,44 @@ def zeldovich_ics(pk_table, n_side: int, boxsize: float, cosmo: Cosmology, a_beg
     elif lpt != 1:
         raise ValueError("lpt must be 1 or 2")
     pos = np.mod(q + psi, boxsize)
+    if return_noise_power:
+        return pos, vel, noise_power
     return pos, vel
+
+
+def concept_power_table(pos, boxsize: float, ngrid: int, pk_table=None, growth: float = 1.0, noise_power=None, nbins: Optional[int] = None):
+    """The columns of a CONCEPT power-spectrum file (PPPMP3M/PP/powerspec/powerspec_a=1.00:10-26; read back by
+    pppmp3mplotter.py:123-134 and Power_compare.py:625-629 with usecols (0, 2, 3, 4)):
+        k (mean |k| of the bin), modes (independent half-space modes), P, P corrected, P linear
+    P from the CIC-deposited, deconvolved, interlaced field (`power_modes`, the settings of NN.param:28-45) in linear |k| bins of
+    width 2 k_fundamental up to the Nyquist frequency. `P linear` = growth^2 x the tabulated linear spectrum averaged over the bin's
+    modes; `P corrected` = P x sum(P_lin) / sum(P_lin |R_k|^2) — CONCEPT's 'realization correction', which removes the cosmic
+    variance of the initial noise R from the estimate (nan columns when no table / noise is given)."""
+    k, p = power_modes(pos, boxsize, ngrid, interlace=True)
+    kf = 2 * np.pi / boxsize
+    kny = np.pi * ngrid / boxsize
+    nb = int(nbins) if nbins else max(1, int(np.ceil((kny - 0.5 * kf) / (2 * kf))))
+    edges = np.linspace(0.5 * kf, kny, nb + 1)
+    which = np.digitize(k, edges) - 1
+    ok = (which >= 0) & (which < nb)
+    cnt = np.bincount(which[ok], minlength=nb)
+    keep = cnt > 0
+    mean = lambda w: (np.bincount(which[ok], weights=w[ok], minlength=nb)[keep] / cnt[keep])
+    out = [mean(k), cnt[keep] // 2, mean(p)]
+    if pk_table is not None:
+        tab = np.asarray(pk_table, np.float64)
+        plin = growth ** 2 * np.exp(np.interp(np.log(k), np.log(tab[:, 0]), np.log(tab[:, 1])))
+        lin = mean(plin)
+        if noise_power is not None and np.asarray(noise_power).size == ngrid ** 3:
+            kv = 2 * np.pi * np.fft.fftfreq(ngrid, d=boxsize / ngrid)
+            kx, ky, kz = np.meshgrid(kv, kv, kv, indexing="ij")
+            r2 = np.asarray(noise_power, np.float64)[np.sqrt(kx ** 2 + ky ** 2 + kz ** 2) > 0]       # same mode order as power_modes
+            out += [out[2] * lin / mean(plin * r2), lin]
+        else:
+            out += [np.full_like(lin, np.nan), lin]
+    else:
+        out += [np.full(keep.sum(), np.nan), np.full(keep.sum(), np.nan)]
+    return tuple(out)
 
 
 def run_pp(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: float, a_end: float = 1.0, nsteps: int = 400,

@@ -24,7 +24,7 @@ def test_cli_generates_ics_runs_and_writes_outputs(tmp_path):
     ps = list((tmp_path / "output").rglob("powerspec_a=1.00"))
     assert len(ps) == 1
     tab = np.loadtxt(ps[0])
-    assert tab.shape[1] == 3 and tab[:, 1].sum() in (8 ** 3 - 1, 8 ** 3 - 2)   # np.histogram may drop the corner mode (edge rounding), as in the reference
+    assert tab.shape[1] == 5 and tab[:, 1].sum() in (8 ** 3 - 1, 8 ** 3 - 2)   # np.histogram may drop the corner mode (edge rounding), as in the reference
     # restart from the written snapshot (initial_conditions by file), tree solver, fp32
     rc = concept.main(["-p", str(f), "--ic", str(snaps[0]), "--steps", "2", "--dtype", "f32", "--solver", "tree"])
     assert rc == 0
@@ -79,3 +79,33 @@ def test_cli_cosmological_p3m_and_pm_follow_the_pp_run(tmp_path):
     f = _write(tmp_path, "p3m")
     with pytest.raises(RuntimeError, match="too coarse"):
         concept.main(["-p", str(f), "--cosmological", "--pk-table", str(tmp_path / "pk.txt"), "--steps", "2"])
+
+
+def test_cli_power_spectrum_file_has_concepts_columns(tmp_path):
+    """The thesis' loaders read CONCEPT's powerspec files with `np.loadtxt(fh, comments='#', usecols=(0, 2, 3, 4))`
+    (PPPMP3M/pppmp3mplotter.py:123-134: k, P, P corrected, P linear); the file written by a cosmological run opens the same way,
+    at the times of `output_times['powerspec']` only, with the realisation-corrected column closer to linear theory at low k."""
+    k = np.logspace(-3, 1, 200)
+    np.savetxt(tmp_path / "pk.txt", np.column_stack([k, 2.0e4 * (k / 0.02) / (1 + (k / 0.02) ** 2) ** 1.6]))
+    f = _write(tmp_path, "p3m")
+    rc = concept.main(["-p", str(f), "--cosmological", "--pk-table", str(tmp_path / "pk.txt"), "--steps", "40", "--dtype", "f32",
+                       "-c", "initial_conditions = {'species': 'matter', 'N': 16**3}",
+                       "-c", "potential_options = {'gridsize': 32, 'interlace': {'gravity': {'p3m': (True, True)}}}",
+                       "-c", "output_dirs['powerspec'] = output_dirs['snapshot'].replace('snapshots', 'powerspec')",
+                       "-c", "output_times = {'snapshot': [1.0], 'powerspec': [0.1, 1.0]}"])
+    assert rc == 0
+    files = sorted((tmp_path / "output").rglob("powerspec_a=*"))
+    assert [p.name for p in files] == ["powerspec_a=0.10", "powerspec_a=1.00"]
+    assert len(list((tmp_path / "output").rglob("snapshot_a=*.hdf5"))) == 1
+    with open(files[0], "r", encoding="utf-8", errors="ignore") as fh:
+        kk, P, P_corr, P_lin = np.loadtxt(fh, comments="#", usecols=(0, 2, 3, 4), unpack=True)       # the reference's call
+    modes = np.loadtxt(files[0], comments="#", usecols=(1,))
+    n1 = np.fft.fftfreq(16, d=1 / 16)
+    nn = np.sqrt(n1[:, None, None] ** 2 + n1[None, :, None] ** 2 + n1[None, None, :] ** 2)
+    inside = ((nn >= 0.5) & (nn < 8.0)).sum()                         # like CONCEPT ('k_max': 'nyquist'): the sphere |k| < k_Nyquist
+    assert abs(modes.sum() * 2 - inside) <= 2 and np.all(np.diff(kk) > 0) and np.all(np.isfinite(P_corr + P_lin))
+    # at a = 0.1 the field is linear: the corrected spectrum follows linear theory far better than the raw one (cosmic variance
+    # of the few low-k modes removed); bins below half the particle Nyquist frequency
+    low = kk < 0.5 * np.pi * 16 / 500.0
+    assert np.abs(P_corr[low] / P_lin[low] - 1).max() < 0.1
+    assert np.abs(P_corr[low] / P_lin[low] - 1).mean() < 0.5 * np.abs(P[low] / P_lin[low] - 1).mean()
