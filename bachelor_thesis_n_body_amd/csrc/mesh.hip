@@ -11,14 +11,17 @@
 //   short range:  a_i += G m_j d [ (r^2+eps^2)^{-3/2} - (erf(alpha r) - 2 alpha r/sqrt(pi) e^{-alpha^2 r^2}) / r^3 ],  r < r_cut
 //
 // Long-range pipeline, all grids fp64, ONE complex-to-complex forward FFT and THREE inverse FFTs per evaluation:
-//   deposit    CIC mass assignment with global_atomic_add_f64; lattice 1 -> real part, the lattice shifted by half a
-//              cell (interlacing) -> imaginary part of the same complex grid                        [HBM/atomic bound]
+//   deposit    CIC mass assignment; lattice 1 -> real part, the lattice shifted by half a cell (interlacing) -> imaginary
+//              part of the same complex grid. n >= 1e5: particles sorted by 8^3-cell brick, both lattices accumulated in
+//              a 10^3-cell LDS tile (ds_add_f64), one global atomic per touched cell; small n: global_atomic_add_f64
+//              per particle and corner                                                              [HBM/atomic bound]
 //   FFT        hipFFT Z2Z forward; the two real fields are separated with the Hermitian symmetry in the k-space kernel
 //   k-space    rho_k = (A_k + B_k e^{-i theta})/2, times Green's function, CIC deconvolution (twice: deposit and
 //              interpolation), i k differentiation; Nyquist planes are zeroed. The six real output fields
 //              (g_x, g_y, g_z on both lattices) are packed pairwise into three complex grids      [HBM bound, 16 B in, 48 B out per mode]
 //   inverse    3 x hipFFT Z2Z backward
-//   gather     CIC interpolation of both lattices to the particles, averaged                         [HBM gather bound]
+//   gather     CIC interpolation of both lattices to the particles, averaged; n >= 1e5: the six force fields of a brick
+//              staged in a 48 KB LDS tile                                                           [HBM gather bound]
 // Short range: particles are sorted (rocPRIM radix sort) by cell of side >= r_cut, then by Morton sub-cell; one 128-thread
 // block per chunk of 128 consecutive particles of a row of cells walks the neighbouring rows, source tiles staged through
 // LDS and read back as wave-uniform broadcasts (the accel_f32.hip pattern); a wave-level vote skips the erfc/exp
@@ -26,6 +29,7 @@
 // minimum image.                                                                                    [VALU bound]
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 #include <hipfft/hipfft.h>
@@ -173,6 +177,136 @@ mesh_gather_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __
   }
 }
 
+/* ------------------------------------------------------------------ LDS-privatised bricks ----
+ * Large particle counts: particles are radix-sorted by the 8^3-cell brick of the mesh they deposit into; one block per
+ * (brick, chunk of <= 1024 particles) accumulates both lattices in a 10^3-cell LDS tile (ds_add_f64) and flushes the tile with
+ * one global atomic per touched cell — (10/8)^3 = 2 global atomics per mesh cell and lattice instead of 8 per particle, all
+ * of them z-contiguous — and the interpolation reads the six force fields of a brick from a 48 KB LDS tile instead of 48
+ * scattered 8-byte loads per particle from L2. */
+constexpr int BR = 8;              // brick edge in mesh cells
+constexpr int BT = BR + 2;         // tile edge: local cells -1 .. BR (lattice 2 reaches one cell below, both one above)
+constexpr int BT3 = BT * BT * BT;
+constexpr int BCH = 1024;          // particles per block
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+brick_key_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, int64_t n, double invh, int N, int nbr,
+                 uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int i0 = wrap_index((long long)floor((double)x[p] * invh), N), j0 = wrap_index((long long)floor((double)y[p] * invh), N),
+            k0 = wrap_index((long long)floor((double)z[p] * invh), N);
+  keys[p] = (uint32_t)(((i0 / BR) * nbr + j0 / BR) * nbr + k0 / BR);
+  idx[p] = (uint32_t)p;
+}
+
+// block -> (brick, first particle, one-past-last particle); false when the block is beyond the last chunk
+__device__ inline bool brick_of_block(const int* __restrict__ brick_start, const int* __restrict__ chunk_off, int nb3, int& brick, int& p0, int& p1) {
+  const int w = blockIdx.x;
+  if (w >= chunk_off[nb3]) return false;
+  int lo = 0, hi = nb3;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= w) lo = mid; else hi = mid; }
+  brick = lo;
+  p0 = brick_start[brick] + (w - chunk_off[brick]) * BCH;
+  p1 = min(brick_start[brick + 1], p0 + BCH);
+  return true;
+}
+
+// CIC weights and brick-local base cell of one particle on lattice `lat` (0: as is, 1: shifted by half a cell)
+struct cic_local { int lx, ly, lz; double wx, wy, wz; };
+template <typename T>
+__device__ inline cic_local cic_in_brick(T px, T py, T pz, double invh, int N, int ox, int oy, int oz, int lat) {
+  const double ux = (double)px * invh, uy = (double)py * invh, uz = (double)pz * invh;
+  const double f1x = floor(ux), f1y = floor(uy), f1z = floor(uz);
+  cic_local r;
+  r.lx = wrap_index((long long)f1x, N) - ox; r.ly = wrap_index((long long)f1y, N) - oy; r.lz = wrap_index((long long)f1z, N) - oz;
+  if (lat == 0) { r.wx = ux - f1x; r.wy = uy - f1y; r.wz = uz - f1z; return r; }
+  const double vx = ux - 0.5, vy = uy - 0.5, vz = uz - 0.5;
+  const double f2x = floor(vx), f2y = floor(vy), f2z = floor(vz);
+  r.lx -= (int)(f1x - f2x); r.ly -= (int)(f1y - f2y); r.lz -= (int)(f1z - f2z);     // 0 or 1 cell lower
+  r.wx = vx - f2x; r.wy = vy - f2y; r.wz = vz - f2z;
+  return r;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+brick_deposit_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, const T* __restrict__ m,
+                     const uint32_t* __restrict__ idx_s, const int* __restrict__ brick_start, const int* __restrict__ chunk_off,
+                     int nb3, int nbr, double invh, int N, int interlace, double* __restrict__ grid) {
+  __shared__ double tile[2][BT3];
+  int brick, p0, p1;
+  if (!brick_of_block(brick_start, chunk_off, nb3, brick, p0, p1)) return;
+  const int ox = (brick / (nbr * nbr)) * BR, oy = ((brick / nbr) % nbr) * BR, oz = (brick % nbr) * BR;
+  for (int t = threadIdx.x; t < BT3; t += 256) { tile[0][t] = 0.0; tile[1][t] = 0.0; }
+  __syncthreads();
+  for (int p = p0 + (int)threadIdx.x; p < p1; p += 256) {
+    const uint32_t q = idx_s[p];
+    const T px = x[q], py = y[q], pz = z[q];
+    const double mass = (double)m[q];
+    for (int lat = 0; lat < (interlace ? 2 : 1); ++lat) {
+      const cic_local c = cic_in_brick(px, py, pz, invh, N, ox, oy, oz, lat);
+      const double wx[2] = {(1.0 - c.wx) * mass, c.wx * mass}, wy[2] = {1.0 - c.wy, c.wy}, wz[2] = {1.0 - c.wz, c.wz};
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int d = 0; d < 2; ++d)
+            atomicAdd(&tile[lat][((c.lx + 1 + a) * BT + (c.ly + 1 + b)) * BT + (c.lz + 1 + d)], (wx[a] * wy[b]) * wz[d]);
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < BT3; t += 256) {
+    const double v0 = tile[0][t], v1 = tile[1][t];
+    if (v0 == 0.0 && v1 == 0.0) continue;
+    const int gx = wrap_index(ox - 1 + t / (BT * BT), N), gy = wrap_index(oy - 1 + (t / BT) % BT, N), gz = wrap_index(oz - 1 + t % BT, N);
+    double* cell = grid + 2 * (((size_t)gx * N + gy) * N + gz);
+    if (v0 != 0.0) atomicAdd(cell, v0);
+    if (v1 != 0.0) atomicAdd(cell + 1, v1);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+brick_gather_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z,
+                    const uint32_t* __restrict__ idx_s, const int* __restrict__ brick_start, const int* __restrict__ chunk_off,
+                    int nb3, int nbr, double invh, int N, const double2* __restrict__ f1, const double2* __restrict__ f2,
+                    const double2* __restrict__ f3, int interlace, T* __restrict__ ax, T* __restrict__ ay, T* __restrict__ az) {
+  __shared__ double tile[6][BT3];        // g_x g_y g_z on lattice 1, then on lattice 2
+  int brick, p0, p1;
+  if (!brick_of_block(brick_start, chunk_off, nb3, brick, p0, p1)) return;
+  const int ox = (brick / (nbr * nbr)) * BR, oy = ((brick / nbr) % nbr) * BR, oz = (brick % nbr) * BR;
+  for (int t = threadIdx.x; t < BT3; t += 256) {
+    const int gx = wrap_index(ox - 1 + t / (BT * BT), N), gy = wrap_index(oy - 1 + (t / BT) % BT, N), gz = wrap_index(oz - 1 + t % BT, N);
+    const size_t cell = ((size_t)gx * N + gy) * N + gz;
+    const double2 a = f1[cell], b = f2[cell];
+    tile[0][t] = a.x; tile[1][t] = a.y; tile[2][t] = b.x;
+    if (interlace) { const double2 c = f3[cell]; tile[3][t] = b.y; tile[4][t] = c.x; tile[5][t] = c.y; }
+  }
+  __syncthreads();
+  for (int p = p0 + (int)threadIdx.x; p < p1; p += 256) {
+    const uint32_t q = idx_s[p];
+    const T px = x[q], py = y[q], pz = z[q];
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int lat = 0; lat < (interlace ? 2 : 1); ++lat) {
+      const cic_local c = cic_in_brick(px, py, pz, invh, N, ox, oy, oz, lat);
+      const double wx[2] = {1.0 - c.wx, c.wx}, wy[2] = {1.0 - c.wy, c.wy}, wz[2] = {1.0 - c.wz, c.wz};
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const int t = ((c.lx + 1 + a) * BT + (c.ly + 1 + b)) * BT + (c.lz + 1 + d);
+            const double w = (wx[a] * wy[b]) * wz[d];
+            sx += w * tile[3 * lat][t]; sy += w * tile[3 * lat + 1][t]; sz += w * tile[3 * lat + 2][t];
+          }
+    }
+    const double sc = interlace ? 0.5 : 1.0;
+    ax[q] = (T)(sc * sx); ay[q] = (T)(sc * sy); az[q] = (T)(sc * sz);
+  }
+}
+
 /* ------------------------------------------------------------------ short range ---- */
 
 template <typename T>
@@ -210,19 +344,19 @@ sort_gather_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __
 
 // cell_start[c] = first sorted position whose key >= c, for c = 0 .. ncell3 (cell_start[ncell3] = n)
 __global__ void __launch_bounds__(256)
-cell_start_kernel(const uint32_t* __restrict__ keys_s, int64_t n, int ncell3, int* __restrict__ cell_start) {
+cell_start_kernel(const uint32_t* __restrict__ keys_s, int64_t n, int ncell3, int shift, int* __restrict__ cell_start) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p > n) return;
-  const int lo = p == 0 ? 0 : (int)(keys_s[p - 1] >> SUBBITS) + 1;
-  const int hi = p == n ? ncell3 : (int)(keys_s[p] >> SUBBITS);
+  const int lo = p == 0 ? 0 : (int)(keys_s[p - 1] >> shift) + 1;
+  const int hi = p == n ? ncell3 : (int)(keys_s[p] >> shift);
   for (int c = lo; c <= hi; ++c) cell_start[c] = (int)p;
 }
 
 __global__ void __launch_bounds__(256)
-chunk_count_kernel(const int* __restrict__ cell_start, int nrows, int nc, int* __restrict__ cnt) {
+chunk_count_kernel(const int* __restrict__ cell_start, int nrows, int nc, int chunk, int* __restrict__ cnt) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r > nrows) return;
-  cnt[r] = r < nrows ? (cell_start[(r + 1) * nc] - cell_start[r * nc] + SRB - 1) / SRB : 0;
+  cnt[r] = r < nrows ? (cell_start[(r + 1) * nc] - cell_start[r * nc] + chunk - 1) / chunk : 0;
 }
 
 // erfc-split pair factor:  (r^2+eps^2)^{-3/2} - (erf(a r) - 2 a r/sqrt(pi) e^{-a^2 r^2}) / r^3
@@ -392,10 +526,10 @@ int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z,
   NB_HIP(c, rocprim::radix_sort_pairs(s.tmp, tb, s.keys, s.keys_s, s.idx, s.idx_s, (size_t)n, 0, (unsigned)bits, st));
   sort_gather_kernel<T, V4><<<nb, 256, 0, st>>>(x, y, z, m, s.idx_s, n, L, (V4*)s.sorted);
   NB_HIP(c, hipGetLastError());
-  cell_start_kernel<<<(int)((n + 1 + 255) / 256), 256, 0, st>>>(s.keys_s, n, ncell3, s.cell_start);
+  cell_start_kernel<<<(int)((n + 1 + 255) / 256), 256, 0, st>>>(s.keys_s, n, ncell3, SUBBITS, s.cell_start);
   NB_HIP(c, hipGetLastError());
   const int nrows = nc * nc;
-  chunk_count_kernel<<<(nrows + 1 + 255) / 256, 256, 0, st>>>(s.cell_start, nrows, nc, s.chunk_cnt);
+  chunk_count_kernel<<<(nrows + 1 + 255) / 256, 256, 0, st>>>(s.cell_start, nrows, nc, SRB, s.chunk_cnt);
   NB_HIP(c, hipGetLastError());
   tb = s.tmp_bytes;
   NB_HIP(c, rocprim::exclusive_scan(s.tmp, tb, s.chunk_cnt, s.chunk_off, 0, (size_t)nrows + 1, rocprim::plus<int>(), st));
@@ -403,6 +537,70 @@ int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z,
   short_range_kernel<T, V4><<<(unsigned)max_chunks, SRB, 0, st>>>((const V4*)s.sorted, s.keys_s, s.cell_start, s.chunk_off, nrows, nc,
                                                                    (T)L, (T)alpha, (T)(rcut * rcut), (T)eps2, G, s.idx_s,
                                                                    ax, ay, az);
+  NB_HIP(c, hipGetLastError());
+  return NB_OK;
+}
+
+// sort the particles by mesh brick and build the (brick, chunk) work list; returns the launch grid in max_chunks
+template <typename T>
+int brick_prepare(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z, int64_t n, double invh, int N, int& nbr, int& nb3,
+                  int64_t& max_chunks) {
+  nbr = (N + BR - 1) / BR;
+  nb3 = nbr * nbr * nbr;
+  int rc = ensure_cells(c, s, n, (int)sizeof(T), nb3);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
+  brick_key_kernel<T><<<(int)((n + 255) / 256), 256, 0, st>>>(x, y, z, n, invh, N, nbr, s.keys, s.idx);
+  NB_HIP(c, hipGetLastError());
+  int bits = 1; while ((1u << bits) < (unsigned)nb3) ++bits;
+  size_t tb = s.tmp_bytes;
+  NB_HIP(c, rocprim::radix_sort_pairs(s.tmp, tb, s.keys, s.keys_s, s.idx, s.idx_s, (size_t)n, 0, (unsigned)bits, st));
+  cell_start_kernel<<<(int)((n + 1 + 255) / 256), 256, 0, st>>>(s.keys_s, n, nb3, 0, s.cell_start);
+  NB_HIP(c, hipGetLastError());
+  chunk_count_kernel<<<(nb3 + 1 + 255) / 256, 256, 0, st>>>(s.cell_start, nb3, 1, BCH, s.chunk_cnt);
+  NB_HIP(c, hipGetLastError());
+  tb = s.tmp_bytes;
+  NB_HIP(c, rocprim::exclusive_scan(s.tmp, tb, s.chunk_cnt, s.chunk_off, 0, (size_t)nb3 + 1, rocprim::plus<int>(), st));
+  max_chunks = (int64_t)nb3 + n / BCH + 1;
+  return NB_OK;
+}
+
+template <typename T>
+int long_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z, const T* m, int64_t n, double L, int ngrid, double rs,
+               int p3m, int interlace, double G, T* ax, T* ay, T* az) {
+  hipStream_t st = c->stream;
+  const double h = L / ngrid;
+  const size_t cells = (size_t)ngrid * ngrid * ngrid;
+  // LDS-privatised bricks pay for their sort from ~10^5 particles on (NB_MESH_BRICKS=0/1 forces the choice)
+  static const char* env = getenv("NB_MESH_BRICKS");
+  const bool bricks = env && *env ? atoi(env) != 0 : n >= 100000;
+  int nbr = 0, nb3 = 0;
+  int64_t max_chunks = 0;
+  if (bricks) { int rc = brick_prepare<T>(c, s, x, y, z, n, 1.0 / h, ngrid, nbr, nb3, max_chunks); if (rc) return rc; }
+  NB_HIP(c, hipMemsetAsync(s.grid[0], 0, cells * sizeof(hipfftDoubleComplex), st));
+  if (bricks) {
+    brick_deposit_kernel<T><<<(unsigned)max_chunks, 256, 0, st>>>(x, y, z, m, s.idx_s, s.cell_start, s.chunk_off, nb3, nbr, 1.0 / h, ngrid,
+                                                                 interlace, (double*)s.grid[0]);
+    NB_HIP(c, hipGetLastError());
+  } else {
+    for (int lat = 0; lat < (interlace ? 2 : 1); ++lat) {
+      mesh_deposit_kernel<T><<<stream_grid(n), 256, 0, st>>>(x, y, z, m, n, 1.0 / h, ngrid, lat ? 0.5 : 0.0, lat, (double*)s.grid[0]);
+      NB_HIP(c, hipGetLastError());
+    }
+  }
+  M_FFT(c, hipfftExecZ2Z(s.fft, s.grid[0], s.grid[0], HIPFFT_FORWARD));
+  const double fac = 4.0 * 3.14159265358979323846 * G / (L * L * L);
+  mesh_kspace_kernel<<<(unsigned)((cells + 255) / 256), 256, 0, st>>>(s.grid[0], s.grid[1], s.grid[2], s.grid[3], ngrid, L, rs, fac,
+                                                                      interlace, p3m);
+  NB_HIP(c, hipGetLastError());
+  for (int g = 1; g <= (interlace ? 3 : 2); ++g) M_FFT(c, hipfftExecZ2Z(s.fft, s.grid[g], s.grid[g], HIPFFT_BACKWARD));
+  if (bricks)
+    brick_gather_kernel<T><<<(unsigned)max_chunks, 256, 0, st>>>(x, y, z, s.idx_s, s.cell_start, s.chunk_off, nb3, nbr, 1.0 / h, ngrid,
+                                                                (const double2*)s.grid[1], (const double2*)s.grid[2],
+                                                                (const double2*)s.grid[3], interlace, ax, ay, az);
+  else
+    mesh_gather_kernel<T><<<stream_grid(n), 256, 0, st>>>(x, y, z, n, 1.0 / h, ngrid, (const double*)s.grid[1], (const double*)s.grid[2],
+                                                          (const double*)s.grid[3], interlace, ax, ay, az);
   NB_HIP(c, hipGetLastError());
   return NB_OK;
 }
@@ -436,32 +634,13 @@ int nb_launch_accel_mesh(nb_ctx* c, int dtype, const void* x, const void* y, con
   if (parts & 1) {
     int rc = ensure_grids(c, s, ngrid);
     if (rc) return rc;
-    const size_t cells = (size_t)ngrid * ngrid * ngrid;
-    NB_HIP(c, hipMemsetAsync(s.grid[0], 0, cells * sizeof(hipfftDoubleComplex), st));
-    for (int lat = 0; lat < (interlace ? 2 : 1); ++lat) {
-      if (dtype == NB_F32)
-        mesh_deposit_kernel<float><<<stream_grid(n), 256, 0, st>>>((const float*)x, (const float*)y, (const float*)z, (const float*)m,
-                                                                   n, 1.0 / h, ngrid, lat ? 0.5 : 0.0, lat, (double*)s.grid[0]);
-      else
-        mesh_deposit_kernel<double><<<stream_grid(n), 256, 0, st>>>((const double*)x, (const double*)y, (const double*)z, (const double*)m,
-                                                                    n, 1.0 / h, ngrid, lat ? 0.5 : 0.0, lat, (double*)s.grid[0]);
-      NB_HIP(c, hipGetLastError());
-    }
-    M_FFT(c, hipfftExecZ2Z(s.fft, s.grid[0], s.grid[0], HIPFFT_FORWARD));
-    const double fac = 4.0 * 3.14159265358979323846 * G / (L * L * L);
-    mesh_kspace_kernel<<<(unsigned)((cells + 255) / 256), 256, 0, st>>>(s.grid[0], s.grid[1], s.grid[2], s.grid[3], ngrid, L, rs, fac,
-                                                                        interlace, p3m);
-    NB_HIP(c, hipGetLastError());
-    for (int g = 1; g <= (interlace ? 3 : 2); ++g) M_FFT(c, hipfftExecZ2Z(s.fft, s.grid[g], s.grid[g], HIPFFT_BACKWARD));
     if (dtype == NB_F32)
-      mesh_gather_kernel<float><<<stream_grid(n), 256, 0, st>>>((const float*)x, (const float*)y, (const float*)z, n, 1.0 / h, ngrid,
-                                                                (const double*)s.grid[1], (const double*)s.grid[2], (const double*)s.grid[3],
-                                                                interlace, (float*)ax, (float*)ay, (float*)az);
+      rc = long_range<float>(c, s, (const float*)x, (const float*)y, (const float*)z, (const float*)m, n, L, ngrid, rs, p3m, interlace, G,
+                             (float*)ax, (float*)ay, (float*)az);
     else
-      mesh_gather_kernel<double><<<stream_grid(n), 256, 0, st>>>((const double*)x, (const double*)y, (const double*)z, n, 1.0 / h, ngrid,
-                                                                 (const double*)s.grid[1], (const double*)s.grid[2], (const double*)s.grid[3],
-                                                                 interlace, (double*)ax, (double*)ay, (double*)az);
-    NB_HIP(c, hipGetLastError());
+      rc = long_range<double>(c, s, (const double*)x, (const double*)y, (const double*)z, (const double*)m, n, L, ngrid, rs, p3m, interlace,
+                              G, (double*)ax, (double*)ay, (double*)az);
+    if (rc) return rc;
   } else {
     NB_HIP(c, hipMemsetAsync(ax, 0, (size_t)n * esz, st));
     NB_HIP(c, hipMemsetAsync(ay, 0, (size_t)n * esz, st));
