@@ -49,6 +49,8 @@ struct nb_mesh_state {
   int *cell_start = nullptr, *chunk_cnt = nullptr, *chunk_off = nullptr;
   void* tmp = nullptr;
   size_t tmp_bytes = 0;
+  float* table = nullptr;            // long-range complement of the pair force tabulated in r^2 (fp32 short-range kernel)
+  double table_alpha = 0.0, table_rcut = 0.0;
 };
 
 namespace {
@@ -359,20 +361,22 @@ chunk_count_kernel(const int* __restrict__ cell_start, int nrows, int nc, int ch
   cnt[r] = r < nrows ? (cell_start[(r + 1) * nc] - cell_start[r * nc] + chunk - 1) / chunk : 0;
 }
 
-// erfc-split pair factor:  (r^2+eps^2)^{-3/2} - (erf(a r) - 2 a r/sqrt(pi) e^{-a^2 r^2}) / r^3
-__device__ inline float sr_factor(float r2, float eps2, float alpha, float c2, float a2l) {
-  const float rinv = r2 > 0.f ? __builtin_amdgcn_rsqf(r2) : 0.f;
-  const float r = r2 * rinv;
-  const float u = alpha * r;
-  const float t = __builtin_amdgcn_exp2f(a2l * r2);
-  const float q = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));           // Abramowitz-Stegun 7.1.26, |err| < 1.5e-7
-  const float poly = q * fmaf(q, fmaf(q, fmaf(q, fmaf(q, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-  const float erf_u = fmaf(-poly, t, 1.0f);
-  const float lng = (erf_u - c2 * r * t) * (rinv * rinv * rinv);
-  const float sinv = __builtin_amdgcn_rsqf(r2 + eps2);
-  const float soft = r2 > 0.f ? sinv * sinv * sinv : 0.f;
-  return soft - lng;
+// fp32 contexts read the long-range complement  T(r^2) = (erf(a r) - 2 a r/sqrt(pi) e^{-a^2 r^2}) / r^3  from a table uniform in
+// r^2 with linear interpolation — as CONCEPT tabulates its short-range force (`shortrange_params` 'tablesize': 4096). T is smooth
+// (T(0) = 4 a^3 / (3 sqrt(pi))): 2048 intervals give 3.5e-7 relative to T, 2e-7 of the Newtonian pair force.
+constexpr int TABN = 2048;
+
+__global__ void __launch_bounds__(256)
+sr_table_kernel(float* __restrict__ table, double alpha, double rcut2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > TABN + 1) return;
+  const double s = rcut2 * (double)i / TABN;
+  double v = 4.0 * alpha * alpha * alpha / (3.0 * 1.7724538509055159);
+  if (s > 1e-12 * rcut2) { const double r = sqrt(s), u = alpha * r; v = (erf(u) - 2.0 * u / 1.7724538509055159 * exp(-u * u)) / (s * r); }
+  table[i] = (float)v;
 }
+
+// erfc-split pair factor (fp64 contexts, exact):  (r^2+eps^2)^{-3/2} - (erf(a r) - 2 a r/sqrt(pi) e^{-a^2 r^2}) / r^3
 __device__ inline double sr_factor(double r2, double eps2, double alpha, double c2, double /*unused*/) {
   if (!(r2 > 0.0)) return 0.0;
   const double r = sqrt(r2), u = alpha * r, rinv = 1.0 / r;
@@ -391,8 +395,11 @@ template <typename T, typename V4>
 __global__ void __launch_bounds__(SRB)
 short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ keys_s, const int* __restrict__ cell_start,
                    const int* __restrict__ chunk_off, int nrows, int nc, T L, T alpha, T rcut2, T eps2, double G,
-                   const uint32_t* __restrict__ idx_s, T* __restrict__ ax, T* __restrict__ ay, T* __restrict__ az) {
+                   const uint32_t* __restrict__ idx_s, const float* __restrict__ table, T* __restrict__ ax, T* __restrict__ ay,
+                   T* __restrict__ az) {
+  constexpr bool TABLE = sizeof(T) == 4;
   __shared__ V4 tile[SRB];
+  __shared__ float tab[TABLE ? TABN + 2 : 1];
   const int total = chunk_off[nrows];
   const int w = blockIdx.x;
   if (w >= total) return;                       // the grid is an upper bound on the number of chunks
@@ -407,7 +414,9 @@ short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ k
   const int i = i_first + (int)threadIdx.x;
   const bool live = i <= i_last;
   const V4 me = sorted[live ? i : i_last];
-  const T c2 = (T)2 * alpha * (T)0.5641895835477563, a2l = -alpha * alpha * (T)1.4426950408889634;
+  const T c2 = (T)2 * alpha * (T)0.5641895835477563, a2l = 0;
+  if (TABLE) for (int t = threadIdx.x; t < TABN + 2; t += SRB) tab[t] = table[t];     // first use is behind the tile barrier
+  const float tscale = TABLE ? (float)TABN / (float)rcut2 : 0.f;
   double tx = 0.0, ty = 0.0, tz = 0.0;
   for (int nb = 0; nb < 9; ++nb) {
     int qx = cx + nb / 3 - 1, qy = cy + nb % 3 - 1;
@@ -439,7 +448,19 @@ short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ k
           // wave-uniform branch: the 64 sinks of a wave are a compact blob (sub-cell sort), most sources of the walked
           // cells are out of reach of all of them and cost only the distance test
           if (__builtin_amdgcn_ballot_w64(r2 < rcut2) != 0) {
-            T f = s.w * sr_factor(r2, eps2, alpha, c2, a2l);
+            T pair;
+            if constexpr (TABLE) {
+              const float t = (float)r2 * tscale;
+              const int it = min((int)t, TABN);                  // lanes beyond the cut-off are masked below
+              const float fr = t - (float)it;
+              const float t0 = tab[it], t1 = tab[it + 1];
+              const float sinv = __builtin_amdgcn_rsqf((float)r2 + (float)eps2);
+              const float soft = r2 > (T)0 ? sinv * sinv * sinv : 0.f;
+              pair = soft - fmaf(fr, t1 - t0, t0);
+            } else {
+              pair = sr_factor(r2, eps2, alpha, c2, a2l);
+            }
+            T f = s.w * pair;
             f = r2 < rcut2 ? f : (T)0;
             fx += f * dx; fy += f * dy; fz += f * dz;
           }
@@ -534,8 +555,14 @@ int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z,
   tb = s.tmp_bytes;
   NB_HIP(c, rocprim::exclusive_scan(s.tmp, tb, s.chunk_cnt, s.chunk_off, 0, (size_t)nrows + 1, rocprim::plus<int>(), st));
   const int64_t max_chunks = (int64_t)nrows + n / SRB + 1;      // sum_r ceil(n_r / SRB) <= nrows + n / SRB
+  if (sizeof(T) == 4 && (!s.table || s.table_alpha != alpha || s.table_rcut != rcut)) {
+    if (!s.table) NB_HIP(c, hipMalloc((void**)&s.table, (TABN + 2) * sizeof(float)));
+    sr_table_kernel<<<(TABN + 2 + 255) / 256, 256, 0, st>>>(s.table, alpha, rcut * rcut);
+    NB_HIP(c, hipGetLastError());
+    s.table_alpha = alpha; s.table_rcut = rcut;
+  }
   short_range_kernel<T, V4><<<(unsigned)max_chunks, SRB, 0, st>>>((const V4*)s.sorted, s.keys_s, s.cell_start, s.chunk_off, nrows, nc,
-                                                                   (T)L, (T)alpha, (T)(rcut * rcut), (T)eps2, G, s.idx_s,
+                                                                   (T)L, (T)alpha, (T)(rcut * rcut), (T)eps2, G, s.idx_s, s.table,
                                                                    ax, ay, az);
   NB_HIP(c, hipGetLastError());
   return NB_OK;
@@ -613,7 +640,7 @@ void nb_mesh_release(nb_ctx* c) {
   for (auto& g : s.grid) if (g) (void)hipFree(g);
   if (s.have_fft) (void)hipfftDestroy(s.fft);
   for (void* p : {(void*)s.keys, (void*)s.keys_s, (void*)s.idx, (void*)s.idx_s, s.sorted, (void*)s.cell_start,
-                  (void*)s.chunk_cnt, (void*)s.chunk_off, s.tmp})
+                  (void*)s.chunk_cnt, (void*)s.chunk_off, s.tmp, (void*)s.table})
     if (p) (void)hipFree(p);
   delete c->mesh;
   c->mesh = nullptr;
