@@ -61,21 +61,34 @@ ewald_real_kernel(const double* __restrict__ x, const double* __restrict__ y, co
   if (live) { ax[i] = G * fx; ay[i] = G * fy; az[i] = G * fz; }
 }
 
-// fp32 version of the real-space sum: v_rsq / v_exp / v_rcp transcendentals, erfc by Abramowitz-Stegun 7.1.26
-// (|error| < 1.5e-7, i.e. 1.5e-7 of the local Newtonian pair force), fp32 partial sums flushed to fp64 per source tile as
-// in accel_f32.hip. ~45 full-rate VALU + 4 transcendentals per interaction.
+// fp32 version of the real-space sum. The long-range complement T(r^2) = (erf(a r) - 2 a r/sqrt(pi) e^{-a^2 r^2}) / r^3 is read
+// from a table uniform in r^2 over [0, 3 L^2/4] (the largest minimum-image separation), 8192 intervals, linear interpolation
+// from LDS: 3.5e-7 of the Newtonian pair force — replaces erfc/exp/rcp arithmetic (~45 full-rate VALU + 4 transcendentals per
+// pair) by ~27 + 1. fp32 partial sums flushed to fp64 per source tile as in accel_f32.hip.
+constexpr int ETAB = 8192;
+
+__global__ void __launch_bounds__(BLOCK)
+ewald_table_kernel(float* __restrict__ table, double alpha, double smax) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > ETAB + 1) return;
+  const double s = smax * (double)i / ETAB;
+  double v = 4.0 * alpha * alpha * alpha / (3.0 * 1.7724538509055159);
+  if (s > 1e-12 * smax) { const double r = sqrt(s), u = alpha * r; v = (erf(u) - 2.0 * u / 1.7724538509055159 * exp(-u * u)) / (s * r); }
+  table[i] = (float)v;
+}
+
 __global__ void __launch_bounds__(BLOCK)
 ewald_real_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                      const float* __restrict__ m, int n, float L, float alpha, float eps2, float G,
-                      float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az) {
+                      const float* __restrict__ m, int n, float L, float tscale, float eps2, float G,
+                      const float* __restrict__ table, float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az) {
   __shared__ float4 tile[BLOCK];
+  __shared__ float tab[ETAB + 2];
+  for (int t = threadIdx.x; t < ETAB + 2; t += BLOCK) tab[t] = table[t];      // first use is behind the tile barrier
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   const bool live = i < n;
   const int ic = live ? i : n - 1;
   const float px = x[ic], py = y[ic], pz = z[ic];
   const float invL = 1.0f / L;
-  const float c2 = 2.0f * alpha * 0.5641895835f;        // 2 alpha / sqrt(pi)
-  const float a2l = -alpha * alpha * 1.4426950409f;     // -alpha^2 log2(e)
   double tx = 0.0, ty = 0.0, tz = 0.0;
   for (int j0 = 0; j0 < n; j0 += BLOCK) {
     __syncthreads();
@@ -92,18 +105,13 @@ ewald_real_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, 
       float dx = s.x - px, dy = s.y - py, dz = s.z - pz;
       dx = fmaf(-L, rintf(dx * invL), dx); dy = fmaf(-L, rintf(dy * invL), dy); dz = fmaf(-L, rintf(dz * invL), dz);
       const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-      const float rinv = r2 > 0.f ? __builtin_amdgcn_rsqf(r2) : 0.f;       // self / coincident: no contribution
-      const float r = r2 * rinv;
-      const float u = alpha * r;
-      const float t = __builtin_amdgcn_exp2f(a2l * r2);                    // e^{-alpha^2 r^2}
-      const float q = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
-      const float poly = q * fmaf(q, fmaf(q, fmaf(q, fmaf(q, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-      const float erf_u = fmaf(-poly, t, 1.0f);                            // 1 - erfc(u)
-      const float rinv3 = rinv * rinv * rinv;
-      const float lng = (erf_u - c2 * r * t) * rinv3;
+      const float t = r2 * tscale;
+      const int it = min((int)t, ETAB);
+      const float fr = t - (float)it;
+      const float t0 = tab[it], t1 = tab[it + 1];
       const float sinv = __builtin_amdgcn_rsqf(r2 + eps2);
-      const float soft = r2 > 0.f ? sinv * sinv * sinv : 0.f;
-      const float f = s.w * (soft - lng);
+      const float soft = r2 > 0.f ? sinv * sinv * sinv : 0.f;                 // self / coincident: no contribution (d = 0)
+      const float f = s.w * (soft - fmaf(fr, t1 - t0, t0));
       fx = fmaf(f, dx, fx); fy = fmaf(f, dy, fy); fz = fmaf(f, dz, fz);
     }
     tx += (double)fx; ty += (double)fy; tz += (double)fz;
@@ -184,12 +192,15 @@ struct nb_ewald_state {
   double* sk = nullptr;     // [2*nk]
   int nk = 0;
   double L = 0, alphaL = 0; int kmax = 0;
+  float* table = nullptr;   // T(r^2) of the fp32 real-space kernel
+  double table_L = 0, table_alphaL = 0;
 };
 
 void nb_ewald_release(nb_ctx* c) {
   if (c->ewald) {
     if (c->ewald->kvec) (void)hipFree(c->ewald->kvec);
     if (c->ewald->sk) (void)hipFree(c->ewald->sk);
+    if (c->ewald->table) (void)hipFree(c->ewald->table);
     delete c->ewald; c->ewald = nullptr;
   }
 }
@@ -239,8 +250,15 @@ int nb_launch_accel_ewald(nb_ctx* c, int dtype, const void* x, const void* y, co
   const size_t lds = 6 * 256 * sizeof(double);
   if (dtype == NB_F32) {
     const float *fx = (const float*)x, *fy = (const float*)y, *fz = (const float*)z, *fm = (const float*)m;
-    ewald_real_f32_kernel<<<nb, BLOCK, 0, c->stream>>>(fx, fy, fz, fm, (int)n, (float)L, (float)alpha, (float)eps2, (float)G,
-                                                       (float*)ax, (float*)ay, (float*)az);
+    const double smax = 0.75 * L * L * (1.0 + 1e-6);           // largest minimum-image r^2
+    if (!e.table || e.table_L != L || e.table_alphaL != alphaL) {
+      if (!e.table) NB_HIP(c, hipMalloc((void**)&e.table, (ETAB + 2) * sizeof(float)));
+      ewald_table_kernel<<<(ETAB + 2 + BLOCK - 1) / BLOCK, BLOCK, 0, c->stream>>>(e.table, alpha, smax);
+      NB_HIP(c, hipGetLastError());
+      e.table_L = L; e.table_alphaL = alphaL;
+    }
+    ewald_real_f32_kernel<<<nb, BLOCK, 0, c->stream>>>(fx, fy, fz, fm, (int)n, (float)L, (float)(ETAB / smax), (float)eps2, (float)G,
+                                                       e.table, (float*)ax, (float*)ay, (float*)az);
     NB_HIP(c, hipGetLastError());
     ewald_sk_kernel<float><<<e.nk, BLOCK, 0, c->stream>>>(fx, fy, fz, fm, (int)n, e.kvec, e.sk);
     NB_HIP(c, hipGetLastError());
