@@ -124,3 +124,35 @@ def test_second_order_ics_are_closer_to_the_nbody_evolution_than_first_order():
     alpha_x = (wrap(truth - p1) * d2).sum() / (d2 * d2).sum()
     alpha_v = ((vtruth - v1) * dv2).sum() / (dv2 * dv2).sum()
     assert 0.8 < alpha_x < 1.2 and 0.8 < alpha_v < 1.2, (alpha_x, alpha_v)
+
+
+def test_growth_between_two_output_times_against_the_reference_run():
+    """SnapVsPK/powerspec/powerspec_a={0.17,1.00} are two output times of ONE CONCEPT `p3m` run (64^3, 1000 Mpc; Uncertain.param):
+    P(a=1)/P(a=1/6) per bin is the growth over that interval of one realisation — 21.9 at the largest scales (linear theory:
+    22.35), a dip to 20.5 near k = 0.05/Mpc, 29.8 at the Nyquist end. The same run here (profiles/r01_growth_ratio_*: 12 seeds,
+    step-count converged) has the same shape; it stays 1-6 % above the reference's curve for 0.02 < k < 0.13 /Mpc (closer to linear
+    theory at the large scales), which is recorded in DESIGN.md as an open difference, and agrees within the seed scatter elsewhere."""
+    early, late = (np.loadtxt(GOLD / f"SnapVsPK_powerspec_a={a}") for a in ("0.17", "1.00"))
+    modes = early[:, 1].astype(int)
+    ref_ratio = late[:, 2] / early[:, 2]
+    lin = np.column_stack([late[:, 0], late[:, 4]])
+    slope = np.log(lin[-1, 1] / lin[-3, 1]) / np.log(lin[-1, 0] / lin[-3, 0])
+    k_ext = np.geomspace(lin[-1, 0] * 1.05, 1.0, 12)
+    tab = np.vstack([lin, np.column_stack([k_ext, lin[-1, 1] * (k_ext / lin[-1, 0]) ** slope])])
+    n_side, L, a_mid, nsteps = 64, 1000.0, 1.0 / 6.0, 200
+    c = cosmo.Cosmology.from_h_omegas(0.6736, 0.02237, 0.12)
+    assert 1.0 / c.growth(a_mid)[0] ** 2 == pytest.approx(late[0, 4] / early[0, 4], rel=2e-4)      # our growth ODE vs CLASS's linear column
+    ratios = []
+    for seed in range(3):
+        pos, vel = cosmo.zeldovich_ics(tab, n_side, L, c, 0.02, 200 + seed, 7000 + seed)
+        mass = c.particle_mass(L, n_side ** 3)
+        n1 = round(nsteps * np.log(a_mid / 0.02) / np.log(1 / 0.02))
+        pos, vel = cosmo.run_pp(pos, vel, mass, L, c, 0.02, a_mid, n1, dtype=np.float32, gravity="p3m", ngrid=64)
+        p_early = cosmo.rebin_like_concept(*cosmo.power_modes(pos, L, n_side, interlace=True), modes)[1]
+        pos, vel = cosmo.run_pp(pos, vel, mass, L, c, a_mid, 1.0, nsteps - n1, dtype=np.float32, gravity="p3m", ngrid=64)
+        p_late = cosmo.rebin_like_concept(*cosmo.power_modes(pos, L, n_side, interlace=True), modes)[1]
+        ratios.append(p_late / p_early)
+    mean = np.mean(ratios, axis=0)
+    assert np.all(np.abs(mean / ref_ratio - 1.0) < 0.09), mean / ref_ratio
+    assert abs(np.mean(mean[:12] / ref_ratio[:12]) - 1.04) < 0.03                    # the recorded systematic difference
+    assert mean[:2] == pytest.approx(22.35, rel=0.03) and mean[-1] > 1.25 * mean[0] and ref_ratio[-1] > 1.25 * ref_ratio[0]
