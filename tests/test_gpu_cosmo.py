@@ -71,8 +71,8 @@ def test_p3m_farm_job_against_the_reference_ensemble():
     """The reference's farm ran 300 independent 32^3 `p3m` jobs (NN.param; Datafolder4/{Test_Data_concept,TrainingVal_Concept});
     tests/golden/concept/p3m_farm_ensemble_pk.txt is the mean P(k) of those 300 snapshots (generator beside it). The same job run
     here for 12 seeds: the ensemble means agree in SHAPE to ~1 % over all bins, with a k-independent offset of -2.5 % in power
-    (32 seeds, 200 steps: 0.975 +- 0.007 in every bin, profiles/r01_p3m_farm_job_32seeds_vs_reference_300_snapshots.txt) — our
-    initial conditions are back-scaled from the a = 1 linear spectrum, CONCEPT realises the CLASS spectrum at a_begin."""
+    (32 seeds, 200 steps: 0.975 +- 0.007 in every bin, profiles/r01_p3m_farm_job_32seeds_vs_reference_300_snapshots.txt) whose origin
+    is not identified (not a force error, not a global IC normalisation)."""
     ens = np.loadtxt(GOLD / "p3m_farm_ensemble_pk.txt")
     edges = np.concatenate([ens[:, 0], ens[-1:, 1]])
     pp = np.loadtxt(TABLE)
