@@ -1,6 +1,6 @@
 """The reference's farm job (TheFeedingPipeline/NN.param: 32^3 particles, 500 Mpc, a = 0.02 -> 1, 'p3m' on a 32^3 mesh,
 interlaced, A_s = 2.105e-9) run here for several seeds; the ensemble-mean P(k) next to the mean over the reference's 300 farm
-snapshots (tests/golden/concept/p3m_farm_ensemble_pk.txt). usage: p3m_farm_ensemble.py [nseeds] [nsteps]"""
+snapshots (tests/golden/concept/p3m_farm_ensemble_pk.txt). usage: p3m_farm_ensemble.py [nseeds] [nsteps] [lpt order]"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +9,7 @@ from bachelor_thesis_n_body_amd import cosmo
 
 nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+lpt = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 gold = os.path.join(ROOT, "tests", "golden", "concept")
 ens = np.loadtxt(os.path.join(gold, "p3m_farm_ensemble_pk.txt"))
 edges = np.concatenate([ens[:, 0], ens[-1:, 1]])
@@ -23,7 +24,7 @@ rows, ic_rows = [], []
 D_ini = c.growth(0.02)[0]
 t0 = time.perf_counter()
 for seed in range(nseeds):
-    pos, vel = cosmo.zeldovich_ics(tab, n_side, L, c, 0.02, 100 + seed, 5000 + seed)
+    pos, vel = cosmo.zeldovich_ics(tab, n_side, L, c, 0.02, 100 + seed, 5000 + seed, lpt=lpt)
     k, p = cosmo.power_modes(pos, L, n_side, interlace=True)       # diagnostic: the initial conditions against D^2 P_lin
     want = D_ini ** 2 * np.exp(np.interp(np.log(k), np.log(tab[:, 0]), np.log(tab[:, 1])))
     which = np.digitize(k, edges) - 1
@@ -38,7 +39,7 @@ for seed in range(nseeds):
 wall = time.perf_counter() - t0
 rows = np.array(rows)
 mean, err = rows.mean(0), rows.std(0, ddof=1) / np.sqrt(nseeds)
-print(f"# {nseeds} seeds x {nsteps} steps of the NN.param job in {wall:.1f} s ({wall/nseeds:.2f} s per job incl. ICs and P(k))")
+print(f"# {lpt}LPT initial conditions; {nseeds} seeds x {nsteps} steps of the NN.param job in {wall:.1f} s ({wall/nseeds:.2f} s per job incl. ICs and P(k))")
 print("#  mean_k    modes   P reference(300 jobs)   P here        +-      ratio")
 for i in range(len(mean)):
     print(f"{ens[i,3]:.4e} {int(ens[i,2]):6d}   {ens[i,4]:.4e}             {mean[i]:.4e}  {err[i]:.1e}  {mean[i]/ens[i,4]:.3f}")
