@@ -41,6 +41,7 @@ SIGNATURES = {
     "nb_step_energy": (_int, [_vp, _dbl, _i64, _dbl, _dbl, _vp, _vp]),
     "nb_accel_dev": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _int]),
     "nb_accel_pot_dev": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp, _int]),
+    "nb_pot_energy_dev": (_int, [_vp, _int, _vp, _vp, _i64, _dbl, _int, _vp]),
     "nb_potential_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _dbl, _vp, _int]),
     "nb_kinetic_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _i64, _vp]),
     "nb_kick_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl]),

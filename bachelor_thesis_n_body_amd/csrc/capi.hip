@@ -437,6 +437,15 @@ int nb_accel_pot_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const
   return nb_fail(c, NB_ERR_ARG, "nb_accel_pot_dev: unknown dtype");
 }
 
+int nb_pot_energy_dev(nb_ctx* c, int dtype, const double* phi, const void* m, int64_t n, double eps, int uniform, double* w_out) {
+  if (!c) return NB_ERR_ARG;
+  if (!phi || !m || !w_out || n < 0) return nb_fail(c, NB_ERR_ARG, "nb_pot_energy_dev: bad argument");
+  if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_pot_energy_dev: unknown dtype");
+  if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_pot_energy_dev: eps must be >= 0");
+  int rc = use_device(c); if (rc) return rc;
+  return nb_launch_pot_energy(c, dtype, phi, m, n, eps * eps, dtype == NB_F32 && uniform, w_out);
+}
+
 int nb_potential_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const void* zi, const void* mi,
                      int64_t n_snk, int64_t snk_global0, const void* xs, const void* ys, const void* zs,
                      const void* ms, int64_t n_src, int64_t src_global0, double eps, double* u_out, int accumulate) {

@@ -102,6 +102,13 @@ class HipKernels:
                                         (_lib.NB_ACCUMULATE if accumulate else 0) | (_lib.NB_UNIFORM_MASS if uniform_mass else 0))
         _lib.check(self._ctx, rc, "nb_accel_pot_dev")
 
+    def pot_energy(self, phi, mass_row, n, eps, out, uniform_mass=False):
+        """out[0] = sum_i m_i (phi_i - self term) for the phi of accel_pot() accumulated over all source chunks."""
+        self._bind()
+        rc = self._lib.nb_pot_energy_dev(self._ctx, self._code(mass_row), C.c_void_p(phi.data_ptr()), C.c_void_p(mass_row.data_ptr()), n,
+                                         eps, int(bool(uniform_mass)), C.c_void_p(out.data_ptr()))
+        _lib.check(self._ctx, rc, "nb_pot_energy_dev")
+
     def potential(self, snk, n_snk, snk_g0, src, n_src, src_g0, eps, out, accumulate):
         self._bind()
         xi, yi, zi, mi = self._rows(snk, 4)
@@ -166,6 +173,7 @@ class ShardedEngine:
         self.ring = [z(4, self.n_max), z(4, self.n_max)] if self.world > 1 else []
         self.gathered = z(self.world, 4, self.n_max) if (self.world > 1 and mode == "allgather") else None
         self.scal = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self.phi = None                # per-sink potential of the fused force+potential kernels (step_with_energy)
         self._acc_key = None
         self.uniform_mass = False
         self.kernel_timer = None   # optional object with begin()/end(interactions): brackets every accel launch
@@ -239,14 +247,19 @@ class ShardedEngine:
                     q.wait()
                 cur = recv_buf
 
-    def accel(self, eps: float, G: float = 1.0) -> None:
-        """acc <- a(x) of the owned sinks due to ALL particles."""
+    def accel(self, eps: float, G: float = 1.0, with_potential: bool = False) -> None:
+        """acc <- a(x) of the owned sinks due to ALL particles; with_potential also accumulates self.phi over the chunks."""
         tm = self.kernel_timer
+        if with_potential and self.phi is None:
+            self.phi = self._torch.zeros(self.n_max, dtype=self._torch.float64, device=self.device)
 
         def one(src, owner, first):
             if tm is not None:
                 tm.begin()
-            self.k.accel(self.pm, self.n_loc, src, self.counts[owner], eps, G, self.acc, not first, self.uniform_mass)
+            if with_potential:
+                self.k.accel_pot(self.pm, self.n_loc, src, self.counts[owner], eps, G, self.acc, self.phi, not first, self.uniform_mass)
+            else:
+                self.k.accel(self.pm, self.n_loc, src, self.counts[owner], eps, G, self.acc, not first, self.uniform_mass)
             if tm is not None:
                 tm.end(float(self.n_loc) * float(self.counts[owner]))
         self._for_each_chunk(one)
@@ -263,6 +276,29 @@ class ShardedEngine:
             self.k.drift(self.pm, self.vel, self.n_loc, dt)
             self.accel(eps, G)
             self.k.kick(self.vel, self.acc, self.n_loc, h)
+
+    def step_with_energy(self, dt: float, nsteps: int = 1, eps: float = 0.0, G: float = 1.0):
+        """KDK steps returning (kinetic[nsteps], potential[nsteps]) of the WHOLE system after every step. The potential is a
+        by-product of the force kernels (`nb_accel_pot_dev` accumulates it over the source chunks as they arrive), so the energy
+        log costs one all-reduce of 2 x nsteps doubles at the end instead of a second ring pass per diagnostic."""
+        t = self._torch
+        log = t.zeros((max(int(nsteps), 0), 2), dtype=t.float64, device=self.device)
+        if nsteps <= 0:
+            return np.empty(0), np.empty(0)
+        if self._acc_key != (eps, G):
+            self.accel(eps, G)
+        h = 0.5 * dt
+        for s in range(int(nsteps)):
+            self.k.kick(self.vel, self.acc, self.n_loc, h)
+            self.k.drift(self.pm, self.vel, self.n_loc, dt)
+            self.accel(eps, G, with_potential=True)
+            self.k.kick(self.vel, self.acc, self.n_loc, h)
+            self.k.kinetic(self.vel, self.pm[3], self.n_loc, log[s, 0:1])
+            self.k.pot_energy(self.phi, self.pm[3], self.n_loc, eps, log[s, 1:2], self.uniform_mass)
+        if self.world > 1:
+            self._dist.all_reduce(log, group=self.group)
+        out = log.cpu().numpy()
+        return out[:, 0].copy(), -0.5 * G * out[:, 1]
 
     def energy(self, eps: float, G: float = 1.0) -> Tuple[float, float]:
         self.k.kinetic(self.vel, self.pm[3], self.n_loc, self.scal[0:1])

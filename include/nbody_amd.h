@@ -124,6 +124,10 @@ int nb_accel_pot_dev(nb_ctx* ctx, int dtype,
                      const void* xi, const void* yi, const void* zi, int64_t n_snk,
                      const void* xs, const void* ys, const void* zs, const void* ms, int64_t n_src,
                      double eps, double G, void* ax, void* ay, void* az, double* phi, int flags);
+/* w_out[0] = sum_{i<n} m_i (phi_i - self_i) (device double), phi from nb_accel_pot_dev over ALL sources; self_i is the i = j term
+ * exactly as the force kernel added it (0 when eps = 0). `uniform` = the NB_UNIFORM_MASS flag the phi was computed with. The
+ * caller sums over ranks and applies -G/2. */
+int nb_pot_energy_dev(nb_ctx* ctx, int dtype, const double* phi, const void* m, int64_t n, double eps, int uniform, double* w_out);
 /* u_out[0] (+)= sum_i m_i sum_{j != i (by global index)} m_j / sqrt(r_ij^2+eps^2)   (device double;
  * the caller applies -G/2). snk_global0 / src_global0 are the global indices of element 0 of each set. */
 int nb_potential_dev(nb_ctx* ctx, int dtype,

@@ -17,6 +17,21 @@ class OracleKernels:
         else:
             out[:, :n_snk] = a.astype(out.dtype)
 
+    def accel_pot(self, snk, n_snk, src, n_src, eps, G, acc, phi, accumulate, uniform_mass=False):
+        self.accel(snk, n_snk, src, n_src, eps, G, acc, accumulate, uniform_mass)
+        s, q = snk.numpy().astype(np.float64), src.numpy().astype(np.float64)
+        d = q[None, :3, :n_src].transpose(0, 2, 1) - s[:3, :n_snk].T[:, None, :]
+        r2 = (d * d).sum(-1) + eps * eps
+        with np.errstate(divide="ignore"):
+            w = np.where(r2 > 0, q[3, :n_src][None, :] / np.sqrt(r2), 0.0)       # no pair skipped except coincident ones at eps = 0
+        p = phi.numpy()
+        p[:n_snk] = (p[:n_snk] if accumulate else 0.0) + w.sum(1)
+
+    def pot_energy(self, phi, mass_row, n, eps, out, uniform_mass=False):
+        m = mass_row.numpy().astype(np.float64)[:n]
+        self_term = m / eps if eps > 0 else 0.0
+        out.numpy()[0] = float((m * (phi.numpy()[:n] - self_term)).sum())
+
     def potential(self, snk, n_snk, snk_g0, src, n_src, src_g0, eps, out, accumulate):
         s, q = snk.numpy().astype(np.float64), src.numpy().astype(np.float64)
         d = q[None, :3, :n_src].transpose(0, 2, 1) - s[:3, :n_snk].T[:, None, :]

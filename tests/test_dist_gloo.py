@@ -41,9 +41,11 @@ def _worker(rank, world, port, n, mode, out_dir):
         eng.step(dt, 3, eps)
         st = eng.gather_state()
         k1, u1 = eng.energy(eps)
+        ks, us = eng.step_with_energy(dt, 2, eps)            # fused potential: energies of steps 4 and 5
+        k2, u2 = eng.energy(eps)
         if rank == 0:
             np.savez(Path(out_dir) / "res.npz", acc0=acc0, pos=st.pos, vel=st.vel, mass=st.mass, acc=st.acc,
-                     e=np.array([k0, u0, k1, u1]))
+                     e=np.array([k0, u0, k1, u1]), fused=np.array([ks[-1], us[-1], k2, u2]), ks=ks, us=us)
     finally:
         dist.destroy_process_group()
 
@@ -67,6 +69,11 @@ def test_sharded_engine_matches_single_process_oracle(tmp_path, world, n, mode):
     np.testing.assert_allclose(r["acc"], o.acc, rtol=1e-11, atol=1e-13)
     np.testing.assert_array_equal(r["mass"], mass)
     np.testing.assert_allclose(r["e"], [k0, u0, k1, u1], rtol=1e-12)
+    # step_with_energy: per-step energies of the whole system, equal to the separate ring pass and to the oracle
+    np.testing.assert_allclose(r["fused"][:2], r["fused"][2:], rtol=1e-12)
+    for i in range(2):
+        ora.step(o, dt, 1, eps=eps)
+        np.testing.assert_allclose([r["ks"][i], r["us"][i]], ora.energy(o, eps), rtol=1e-11)
 
 
 def test_single_rank_engine_without_process_group():

@@ -41,8 +41,10 @@ def _worker(rank, world, port, n, mode, dtype_name, out_dir):
         eng.step(1 / 256, 3, 0.01)
         st = eng.gather_state()
         k, u = eng.energy(0.01)
+        ks, us = eng.step_with_energy(1 / 256, 2, 0.01)       # fused force+potential kernels, phi accumulated over the chunks
+        k2, u2 = eng.energy(0.01)                               # the separate ring pass at the same state
         if rank == 0:
-            np.savez(Path(out_dir) / "res.npz", acc0=acc0, pos=st.pos, vel=st.vel, e=np.array([k, u]))
+            np.savez(Path(out_dir) / "res.npz", acc0=acc0, pos=st.pos, vel=st.vel, e=np.array([k, u]), ks=ks, us=us, e2=np.array([k2, u2]))
     finally:
         dist.destroy_process_group()
 
@@ -67,3 +69,12 @@ def test_two_ranks_on_one_gpu_match_the_single_engine(tmp_path, n, mode, dtype_n
     assert np.abs(r["acc0"] - acc0).max() < tol * scale
     assert np.abs(r["pos"] - ref.pos).max() < tol * 10 and np.abs(r["vel"] - ref.vel).max() < tol * 10
     assert r["e"][0] == pytest.approx(k, rel=1e-6) and r["e"][1] == pytest.approx(u, rel=1e-6)
+    # sharded step_with_energy: last logged energies = the separate potential/kinetic ring pass; whole log = the single engine's
+    etol = 3e-6 if dtype_name == "f32" else 1e-11
+    assert r["ks"][-1] == pytest.approx(r["e2"][0], rel=1e-12) and r["us"][-1] == pytest.approx(r["e2"][1], rel=etol)
+    with nb.Engine(n, dtype) as e:
+        e.set_state(s)
+        e.step(1 / 256, 3, 0.01)
+        K, U = e.step_with_energy(1 / 256, 2, 0.01)
+    np.testing.assert_allclose(r["ks"], K, rtol=1e-5 if dtype_name == "f32" else 1e-11)
+    np.testing.assert_allclose(r["us"], U, rtol=etol)
