@@ -634,6 +634,21 @@ int long_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z, 
 
 }  // namespace
 
+// The cell-list pair sum on its own — the real-space part of an Ewald sum with a cut-off (ewald.hip): ADDS
+// G m_j d [ (r^2+eps^2)^{-3/2} - (erf(alpha r) - 2 alpha r/sqrt(pi) e^{-alpha^2 r^2}) / r^3 ] over r < rcut to ax, ay, az.
+int nb_launch_short_range(nb_ctx* c, int dtype, const void* x, const void* y, const void* z, const void* m, int64_t n, double L,
+                          double alpha, double rcut, double eps2, double G, void* ax, void* ay, void* az) {
+  if (n <= 0) return NB_OK;
+  const int nc = (int)floor(L / rcut);
+  if (nc < 3) return nb_fail(c, NB_ERR_ARG, "short-range sum: the cut-off exceeds a third of the box");
+  if (!c->mesh) c->mesh = new nb_mesh_state();
+  if (dtype == NB_F32)
+    return short_range<float, float4>(c, *c->mesh, (const float*)x, (const float*)y, (const float*)z, (const float*)m, n, L, nc, alpha, rcut,
+                                      eps2, G, (float*)ax, (float*)ay, (float*)az);
+  return short_range<double, d4>(c, *c->mesh, (const double*)x, (const double*)y, (const double*)z, (const double*)m, n, L, nc, alpha, rcut,
+                                 eps2, G, (double*)ax, (double*)ay, (double*)az);
+}
+
 void nb_mesh_release(nb_ctx* c) {
   if (!c->mesh) return;
   nb_mesh_state& s = *c->mesh;

@@ -73,6 +73,8 @@ void nb_ewald_release(nb_ctx* c);
 int nb_launch_accel_mesh(nb_ctx* c, int dtype, const void* x, const void* y, const void* z, const void* m, int64_t n,
                          double L, int ngrid, double rs_cells, double rcut_rs, int p3m, int interlace, int parts,
                          double eps2, double G, void* ax, void* ay, void* az);
+int nb_launch_short_range(nb_ctx* c, int dtype, const void* x, const void* y, const void* z, const void* m, int64_t n, double L,
+                          double alpha, double rcut, double eps2, double G, void* ax, void* ay, void* az);   // ADDS to acc
 void nb_mesh_release(nb_ctx* c);
 void nb_bh_release(nb_ctx* c);
 int nb_bh_check(nb_ctx* c);   // call after a stream sync
