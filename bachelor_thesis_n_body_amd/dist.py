@@ -223,7 +223,13 @@ class ShardedEngine:
         if P == 1:
             fn(self.pm, r, True)
             return
+        # RCCL/NCCL collectives are ordered after the work already enqueued on the compute stream, so a receive into a buffer the
+        # previous kernel is still reading is safe. Other backends (gloo moving device tensors: the one-GPU rehearsal of
+        # tests/test_gpu_dist.py) give no such ordering: drain the compute stream before every exchange there.
+        unordered = self.device.type == "cuda" and dist.get_backend(self.group) != "nccl"
+        fence = (lambda: self._torch.cuda.current_stream(self.device).synchronize()) if unordered else (lambda: None)
         if self.mode == "allgather":
+            fence()
             work = dist.all_gather_into_tensor(self.gathered.view(-1), self.pm.view(-1), group=self.group, async_op=True)
             fn(self.pm, r, True)          # own chunk overlaps the collective
             work.wait()
@@ -238,6 +244,7 @@ class ShardedEngine:
         for h in range(P):
             reqs = None
             if h < P - 1:
+                fence()
                 recv_buf = self.ring[h & 1]
                 ops = [dist.P2POp(dist.isend, cur, nxt_rank, self.group), dist.P2POp(dist.irecv, recv_buf, prv_rank, self.group)]
                 reqs = dist.batch_isend_irecv(ops)   # posted before the kernel so it runs beside it

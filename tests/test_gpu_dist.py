@@ -49,10 +49,11 @@ def _worker(rank, world, port, n, mode, dtype_name, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,mode,dtype_name", [(6001, "ring", "f32"), (4096, "allgather", "f64")])
-def test_two_ranks_on_one_gpu_match_the_single_engine(tmp_path, n, mode, dtype_name):
+@pytest.mark.parametrize("world,n,mode,dtype_name", [(2, 6001, "ring", "f32"), (2, 4096, "allgather", "f64"), (4, 8191, "ring", "f32")])
+def test_two_ranks_on_one_gpu_match_the_single_engine(tmp_path, world, n, mode, dtype_name):
+    """2 and 4 ranks (uneven shards) sharing the one GPU of the box — at most 6 processes may use it."""
     import bachelor_thesis_n_body_amd as nb
-    mp.spawn(_worker, args=(2, _free_port(), n, mode, dtype_name, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, mode, dtype_name, str(tmp_path)), nprocs=world, join=True)
     r = np.load(tmp_path / "res.npz")
     dtype = np.float32 if dtype_name == "f32" else np.float64
     s = nb.plummer_sphere(n, 5, dtype)
