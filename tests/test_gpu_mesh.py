@@ -136,3 +136,44 @@ def test_steps_wrap_positions_and_track_the_ewald_trajectory(dtype):
     by_force = wrap(out["ewald"].pos.astype(np.float64) - (pos + vel * (0.05 * 20)))      # what gravity did to the orbits
     rms = lambda a: np.sqrt((a * a).sum(1).mean())
     assert rms(d) < 0.05 * rms(by_force)          # same trajectories up to the sub-percent force error of the mesh
+
+
+@pytest.mark.parametrize("ngrid,interlace,dtype", [(27, True, np.float64), (50, False, np.float64), (64, True, np.float32), (9, True, np.float64)])
+def test_long_range_through_lds_bricks_matches_oracle(ngrid, interlace, dtype):
+    """n >= 1e5 takes the brick-sorted, LDS-privatised deposit and gather: mesh sizes that are not multiples of the 8-cell brick,
+    a mesh smaller than one brick tile, particles far outside the box, clustered (one brick holds a third of the particles)."""
+    L, n = 75.0, 120_000
+    rng = np.random.default_rng(ngrid)
+    pos = rng.uniform(-L, 2 * L, (n, 3))
+    pos[: n // 3] = 0.4 * L + 0.02 * L * rng.normal(size=(n // 3, 3))
+    m = rng.uniform(0.5, 1.5, n)
+    rs = 1.25 * L / ngrid
+    p = pos.astype(dtype).astype(np.float64); mm = m.astype(dtype).astype(np.float64)
+    ref = mo.mesh_accel(p, mm, L, ngrid, 1.0, rs if ngrid >= 27 else None, interlace)
+    if ngrid >= 27:
+        got = _accel(pos, m, dtype, L, "p3m", ngrid, 0.1, part="long", interlace=interlace)
+    else:
+        got = _accel(pos, m, dtype, L, "pm", ngrid, interlace=interlace)
+    assert np.abs(got - ref).max() < (1e-9 if dtype == np.float64 else 5e-6) * _scale(ref)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_short_range_random_configurations(seed):
+    """Small random set-ups of the cell-list pair sum: few particles (all lanes of a block idle but a few), the minimum of 3 cells
+    per side, zero softening, every particle in one cell, unequal masses, both precisions."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.choice([3, 50, 129, 700, 2500]))
+    ngrid = int(rng.choice([17, 24, 33, 48]))
+    L = float(rng.choice([10.0, 333.0]))
+    eps = float(rng.choice([0.0, 0.01 * L / ngrid, 0.5 * L / ngrid]))
+    dtype = DTYPES[seed % 2]
+    pos = rng.uniform(0, L, (n, 3))
+    if seed % 3 == 0:
+        pos = np.mod(0.3 * L + 0.3 * (L / ngrid) * rng.normal(size=(n, 3)), L)        # one cell
+    m = rng.uniform(0.1, 3.0, n)
+    p = pos.astype(dtype).astype(np.float64); mm = m.astype(dtype).astype(np.float64)
+    rs = 1.25 * L / ngrid
+    ref = mo.short_range_accel(p, mm, L, rs, 4.5 * rs, eps)
+    got = _accel(pos, m, dtype, L, "p3m", ngrid, eps, part="short")
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < (1e-10 if dtype == np.float64 else 3e-5) * max(_scale(ref), 1e-300)
