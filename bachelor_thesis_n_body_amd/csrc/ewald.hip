@@ -248,23 +248,32 @@ int nb_launch_accel_ewald(nb_ctx* c, int dtype, const void* x, const void* y, co
   }
   const int nb = (int)((n + BLOCK - 1) / BLOCK);
   const size_t lds = 6 * 256 * sizeof(double);
+  // A splitting parameter large enough that the real-space terms have died out (alpha r = 3.3: 7e-5 of the pair force) within a
+  // third of the box turns the all-pairs minimum-image sum into the cell-list pair sum of mesh.hip: 27 of nc^3 cells per sink.
+  const double rcut = 3.3 / alpha;
+  if (rcut <= L / 3.0 && n >= 4096) {
+    const size_t eb = dtype == NB_F32 ? sizeof(float) : sizeof(double);
+    NB_HIP(c, hipMemsetAsync(ax, 0, (size_t)n * eb, c->stream));
+    NB_HIP(c, hipMemsetAsync(ay, 0, (size_t)n * eb, c->stream));
+    NB_HIP(c, hipMemsetAsync(az, 0, (size_t)n * eb, c->stream));
+    int rc = nb_launch_short_range(c, dtype, x, y, z, m, n, L, alpha, rcut, eps2, G, ax, ay, az);
+    if (rc) return rc;
+    if (dtype == NB_F32) {
+      ewald_sk_kernel<float><<<e.nk, BLOCK, 0, c->stream>>>((const float*)x, (const float*)y, (const float*)z, (const float*)m, (int)n, e.kvec, e.sk);
+      NB_HIP(c, hipGetLastError());
+      ewald_recip_kernel<float><<<nb, BLOCK, lds, c->stream>>>((const float*)x, (const float*)y, (const float*)z, (int)n, e.kvec, e.sk, e.nk, G,
+                                                               (float*)ax, (float*)ay, (float*)az);
+    } else {
+      ewald_sk_kernel<double><<<e.nk, BLOCK, 0, c->stream>>>((const double*)x, (const double*)y, (const double*)z, (const double*)m, (int)n, e.kvec, e.sk);
+      NB_HIP(c, hipGetLastError());
+      ewald_recip_kernel<double><<<nb, BLOCK, lds, c->stream>>>((const double*)x, (const double*)y, (const double*)z, (int)n, e.kvec, e.sk, e.nk, G,
+                                                                (double*)ax, (double*)ay, (double*)az);
+    }
+    NB_HIP(c, hipGetLastError());
+    return NB_OK;
+  }
   if (dtype == NB_F32) {
     const float *fx = (const float*)x, *fy = (const float*)y, *fz = (const float*)z, *fm = (const float*)m;
-    // A splitting parameter large enough that the real-space terms have died out (alpha r = 3.3: 7e-5 of the pair force) within
-    // a third of the box turns the all-pairs minimum-image sum into the cell-list sum of mesh.hip: 27 of nc^3 cells per sink.
-    const double rcut = 3.3 / alpha;
-    if (rcut <= L / 3.0 && n >= 4096) {
-      NB_HIP(c, hipMemsetAsync(ax, 0, (size_t)n * sizeof(float), c->stream));
-      NB_HIP(c, hipMemsetAsync(ay, 0, (size_t)n * sizeof(float), c->stream));
-      NB_HIP(c, hipMemsetAsync(az, 0, (size_t)n * sizeof(float), c->stream));
-      int rc = nb_launch_short_range(c, NB_F32, x, y, z, m, n, L, alpha, rcut, eps2, G, ax, ay, az);
-      if (rc) return rc;
-      ewald_sk_kernel<float><<<e.nk, BLOCK, 0, c->stream>>>(fx, fy, fz, fm, (int)n, e.kvec, e.sk);
-      NB_HIP(c, hipGetLastError());
-      ewald_recip_kernel<float><<<nb, BLOCK, lds, c->stream>>>(fx, fy, fz, (int)n, e.kvec, e.sk, e.nk, G, (float*)ax, (float*)ay, (float*)az);
-      NB_HIP(c, hipGetLastError());
-      return NB_OK;
-    }
     const double smax = 0.75 * L * L * (1.0 + 1e-6);           // largest minimum-image r^2
     if (!e.table || e.table_L != L || e.table_alphaL != alphaL) {
       if (!e.table) NB_HIP(c, hipMalloc((void**)&e.table, (ETAB + 2) * sizeof(float)));

@@ -101,28 +101,35 @@ def test_linear_growth_of_a_zeldovich_field():
     assert np.median(ratio) == pytest.approx(D1 / D0, rel=0.03)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("clustered", [False, True])
-def test_ewald_fp32_cell_list_real_space_sum(clustered):
-    """fp32 contexts with alpha_L >= 9.9 sum the real-space part from cell lists (cut-off at alpha r = 3.3) instead of over all
-    minimum-image pairs: same forces as the converged oracle and as the all-pairs fp32 path, to the fp32 level."""
+def test_ewald_cell_list_real_space_sum(clustered, dtype):
+    """With alpha_L >= 9.9 the real-space part is summed from cell lists (cut-off at alpha r = 3.3) instead of over all
+    minimum-image pairs: same forces as the converged oracle and as the all-pairs path, to the truncation / fp32 level."""
     rng = np.random.default_rng(11)
-    n, L, eps = 6000, 80.0, 0.2
+    n, L, eps = 5000, 80.0, 0.2
     pos = rng.uniform(0, L, (n, 3))
     if clustered:
         pos[: n // 2] = np.mod(40.0 + 2.0 * rng.normal(size=(n // 2, 3)), L)
-    pos, m = pos.astype(np.float32), rng.uniform(0.5, 2.0, n).astype(np.float32)
+    pos, m = pos.astype(dtype), rng.uniform(0.5, 2.0, n).astype(dtype)
 
     def run(aL, kmax):
-        with nb.Engine(n, np.float32) as e:
+        with nb.Engine(n, dtype) as e:
             e.set_periodic(L, aL, kmax)
             e.set_state(nb.State(pos, np.zeros_like(pos), m))
             return e.accel(eps, 2.0).astype(np.float64)
     cells, pairs = run(13.2, 15), run(6.2, 7)
-    sub = slice(0, 400)
-    ref = eo.ewald_accel(pos.astype(np.float64), m.astype(np.float64), L, eps, G=2.0, alpha_L=7.5, kmax=13, images=1)[sub]
-    scale = np.sqrt((ref ** 2).sum(1).mean())
-    assert np.abs(cells[sub] - ref).max() < 1e-4 * scale and np.sqrt(((cells[sub] - ref) ** 2).sum(1).mean()) < 2e-5 * scale
-    assert np.abs(cells - pairs).max() < 1e-4 * scale
+    scale = np.sqrt((pairs ** 2).sum(1).mean())
+    assert np.abs(cells - pairs).max() < 1e-4 * scale and np.sqrt(((cells - pairs) ** 2).sum(1).mean()) < 2e-5 * scale
+    if dtype == np.float64 and not clustered:                            # and both against the converged CPU sum (27 images, kmax 13)
+        k = 2500
+        sub_pos, sub_m = pos[:k], m[:k]
+        with nb.Engine(k, dtype) as e:
+            e.set_periodic(L, 13.2, 15)
+            e.set_state(nb.State(sub_pos, np.zeros_like(sub_pos), sub_m))
+            got = e.accel(eps, 2.0)                                       # k < 4096: all-pairs path with the same splitting
+        ref = eo.ewald_accel(sub_pos, sub_m, L, eps, G=2.0, alpha_L=7.5, kmax=13, images=1)
+        assert np.abs(got - ref).max() < 3e-5 * np.abs(ref).max()
     with nb.Engine(n, np.float32) as e:                                  # kmax range of the API
         with pytest.raises(RuntimeError, match="kmax"):
             e.set_periodic(L, 13.2, 25)
