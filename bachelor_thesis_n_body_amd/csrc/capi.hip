@@ -133,7 +133,7 @@ int nb_set_periodic(nb_ctx* c, double boxsize, double alpha_L, int kmax) {
   if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
   c->acc_valid = false;
   if (!(boxsize > 0.0)) { c->solver = NB_SOLVER_DIRECT; c->box = 0.0; return NB_OK; }
-  if (!(alpha_L > 0.0) || kmax < 1 || kmax > 24) return nb_fail(c, NB_ERR_ARG, "nb_set_periodic: alpha_L must be > 0 and kmax in [1, 24]");
+  if (!(alpha_L > 0.0) || kmax < 1 || kmax > 31) return nb_fail(c, NB_ERR_ARG, "nb_set_periodic: alpha_L must be > 0 and kmax in [1, 31]");
   c->solver = NB_SOLVER_EWALD; c->box = boxsize; c->alphaL = alpha_L; c->kmax = kmax;
   return NB_OK;
 }

@@ -9,11 +9,16 @@
 // term is < 2e-5 of the Newtonian force at the minimum-image boundary r = L/2 and kmax = 7 leaves e^{-k^2/4 alpha^2} < 1e-5.
 //   ewald_real_kernel   all-pairs, LDS-tiled like accel_f64 (sources as (x,y,z,m) in LDS, wave-uniform reads), minimum image
 //                       by x - L rint(x/L); bounded by the fp64 VALU rate (+ erf/exp).
-//   ewald_sk_kernel     one block per k-vector (half space): fixed-order block reduction of m cos / m sin over all particles.
-//   ewald_recip_kernel  one lane per particle: loops over the k-vectors (S_c, S_s, weights in LDS), sincos per (particle, k).
+//   ewald_real_f32_kernel  the same with the long-range complement from an LDS table (fp32 contexts).
+//   With alpha L >= 9.9 (and n >= 4096) the real-space terms have died out within a third of the box and the real-space part is
+//   the cell-list pair sum of mesh.hip (nb_launch_short_range) instead; alpha L = 16.5, kmax = 19 is ~4x faster than 6.2 / 7.
+//   ewald_sk_rows_kernel / ewald_recip_rows_kernel  reciprocal sum over ROWS of k-vectors (fixed n_x, n_y) by complex rotation:
+//                       one sincos per row and particle, 4 fma per k-vector; fixed-order reductions.
+//   ewald_sk_kernel / ewald_recip_kernel  the plain version, one fp64 sincos per (particle, k) (NB_EWALD_ROWS=0).
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -174,6 +179,91 @@ ewald_recip_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __
   if (live) { ax[i] = (T)((double)ax[i] + G * fx); ay[i] = (T)((double)ay[i] + G * fy); az[i] = (T)((double)az[i] + G * fz); }
 }
 
+// ---- reciprocal sum by rows of k-vectors -------------------------------------------------------------------------
+// The half-space table is ordered (a, b, c) with c innermost, so the k-vectors of one (a, b) form a contiguous ROW whose members
+// differ by the constant step dk = 2 pi / L along z: e^{i k.x} of the whole row follows from ONE sincos of the row's first phase
+// and ONE sincos of dk z per particle by complex rotation (4 fma per k-vector instead of an fp64 sincos).
+constexpr int ROWC = 32;        // k-vectors per pass of a row (rows of kmax <= 15 have <= 31)
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK)
+ewald_sk_rows_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, const T* __restrict__ m, int n,
+                     const double* __restrict__ kvec, const int2* __restrict__ rows, double dk, double* __restrict__ sk) {
+  const int2 row = rows[blockIdx.x];
+  __shared__ double red[BLOCK / 64][2 * ROWC];
+  for (int c0 = 0; c0 < row.y; c0 += ROWC) {
+    const int q0 = row.x + c0, cnt = min(ROWC, row.y - c0);
+    const double kx = kvec[4 * q0], ky = kvec[4 * q0 + 1], kz = kvec[4 * q0 + 2];
+    double sc[ROWC], ss[ROWC];
+#pragma unroll
+    for (int e = 0; e < ROWC; ++e) { sc[e] = 0.0; ss[e] = 0.0; }
+    for (int j = threadIdx.x; j < n; j += BLOCK) {
+      const double pz = (double)z[j], mj = (double)m[j];
+      double s, c, ds, dc;
+      sincos(kx * (double)x[j] + ky * (double)y[j] + kz * pz, &s, &c);
+      sincos(dk * pz, &ds, &dc);
+#pragma unroll
+      for (int e = 0; e < ROWC; ++e) {
+        sc[e] = fma(mj, c, sc[e]); ss[e] = fma(mj, s, ss[e]);
+        const double cn = c * dc - s * ds;
+        s = fma(s, dc, c * ds); c = cn;
+      }
+    }
+    // fixed-order reduction: lanes of a wave by shuffles, then the waves through LDS
+#pragma unroll
+    for (int e = 0; e < ROWC; ++e) {
+      double a = sc[e], b = ss[e];
+      for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+      if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][2 * e] = a; red[threadIdx.x >> 6][2 * e + 1] = b; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * cnt) {
+      double t = 0.0;
+      for (int w = 0; w < BLOCK / 64; ++w) t += red[w][threadIdx.x];
+      sk[2 * q0 + threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK)
+ewald_recip_rows_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, int n,
+                        const double* __restrict__ kvec, const double* __restrict__ sk, const int2* __restrict__ rows, int nrows,
+                        double dk, double G, T* __restrict__ ax, T* __restrict__ ay, T* __restrict__ az) {
+  constexpr int MAXROW = 64;                               // >= 2 kmax + 1 for kmax <= 31
+  __shared__ double w[MAXROW], sc[MAXROW], ss[MAXROW];
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  const bool live = i < n;
+  const int ic = live ? i : n - 1;
+  const double px = (double)x[ic], py = (double)y[ic], pz = (double)z[ic];
+  double ds, dc;
+  sincos(dk * pz, &ds, &dc);
+  double fx = 0.0, fy = 0.0, fz = 0.0;
+  for (int r = 0; r < nrows; ++r) {
+    const int2 row = rows[r];
+    __syncthreads();
+    if ((int)threadIdx.x < row.y) {
+      const int q = row.x + threadIdx.x;
+      w[threadIdx.x] = kvec[4 * q + 3]; sc[threadIdx.x] = sk[2 * q]; ss[threadIdx.x] = sk[2 * q + 1];
+    }
+    __syncthreads();
+    const double kx = kvec[4 * row.x], ky = kvec[4 * row.x + 1], kz0 = kvec[4 * row.x + 2];
+    double s, c;
+    sincos(kx * px + ky * py + kz0 * pz, &s, &c);
+    double t0 = 0.0, tz = 0.0, kz = kz0;
+    for (int e = 0; e < row.y; ++e) {
+      const double t = -w[e] * (sc[e] * s - ss[e] * c);
+      t0 += t; tz = fma(t, kz, tz);
+      const double cn = c * dc - s * ds;
+      s = fma(s, dc, c * ds); c = cn;
+      kz += dk;
+    }
+    fx = fma(t0, kx, fx); fy = fma(t0, ky, fy); fz += tz;
+  }
+  if (live) { ax[i] = (T)((double)ax[i] + G * fx); ay[i] = (T)((double)ay[i] + G * fy); az[i] = (T)((double)az[i] + G * fz); }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(BLOCK)
 wrap_kernel(T* __restrict__ x, T* __restrict__ y, T* __restrict__ z, int64_t n, T L) {
@@ -192,6 +282,8 @@ struct nb_ewald_state {
   double* sk = nullptr;     // [2*nk]
   int nk = 0;
   double L = 0, alphaL = 0; int kmax = 0;
+  int2* rows = nullptr;     // (first k index, count) of every (a, b) row of the table
+  int nrows = 0;
   float* table = nullptr;   // T(r^2) of the fp32 real-space kernel
   double table_L = 0, table_alphaL = 0;
 };
@@ -201,6 +293,7 @@ void nb_ewald_release(nb_ctx* c) {
     if (c->ewald->kvec) (void)hipFree(c->ewald->kvec);
     if (c->ewald->sk) (void)hipFree(c->ewald->sk);
     if (c->ewald->table) (void)hipFree(c->ewald->table);
+    if (c->ewald->rows) (void)hipFree(c->ewald->rows);
     delete c->ewald; c->ewald = nullptr;
   }
 }
@@ -215,17 +308,38 @@ int nb_launch_wrap(nb_ctx* c, int dtype, void* x, void* y, void* z, int64_t n, d
   return NB_OK;
 }
 
+// structure factors + reciprocal force (ADDS to acc); rows of k-vectors by rotation unless NB_EWALD_ROWS=0
+template <typename T>
+static int launch_recip(nb_ctx* c, nb_ewald_state& e, const T* x, const T* y, const T* z, const T* m, int64_t n, double L, double G,
+                        T* ax, T* ay, T* az) {
+  static const bool by_rows = !(getenv("NB_EWALD_ROWS") && atoi(getenv("NB_EWALD_ROWS")) == 0);
+  const int nb = (int)((n + BLOCK - 1) / BLOCK);
+  const double dk = 2.0 * 3.14159265358979323846 / L;
+  if (by_rows) {
+    ewald_sk_rows_kernel<T><<<e.nrows, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, e.kvec, e.rows, dk, e.sk);
+    NB_HIP(c, hipGetLastError());
+    ewald_recip_rows_kernel<T><<<nb, BLOCK, 0, c->stream>>>(x, y, z, (int)n, e.kvec, e.sk, e.rows, e.nrows, dk, G, ax, ay, az);
+  } else {
+    ewald_sk_kernel<T><<<e.nk, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, e.kvec, e.sk);
+    NB_HIP(c, hipGetLastError());
+    ewald_recip_kernel<T><<<nb, BLOCK, 6 * 256 * sizeof(double), c->stream>>>(x, y, z, (int)n, e.kvec, e.sk, e.nk, G, ax, ay, az);
+  }
+  NB_HIP(c, hipGetLastError());
+  return NB_OK;
+}
+
 int nb_launch_accel_ewald(nb_ctx* c, int dtype, const void* x, const void* y, const void* z, const void* m, int64_t n,
                           double L, double alphaL, int kmax, double eps2, double G, void* ax, void* ay, void* az) {
   if (n <= 0) return NB_OK;
   if (n >= (1ll << 31)) return nb_fail(c, NB_ERR_ARG, "ewald: n must be < 2^31");
-  if (!(L > 0.0) || !(alphaL > 0.0) || kmax < 1 || kmax > 24) return nb_fail(c, NB_ERR_ARG, "ewald: bad box / alpha / kmax");
+  if (!(L > 0.0) || !(alphaL > 0.0) || kmax < 1 || kmax > 31) return nb_fail(c, NB_ERR_ARG, "ewald: bad box / alpha / kmax");
   if (!c->ewald) c->ewald = new nb_ewald_state();
   nb_ewald_state& e = *c->ewald;
   const double alpha = alphaL / L;
   if (e.L != L || e.alphaL != alphaL || e.kmax != kmax) {
     // k-vector table: half space (first non-zero component positive), |n| <= kmax
     std::vector<double> kv;
+    std::vector<int> rows;                                   // (first k index, count) per (a, b): members contiguous, c ascending
     const double PI = 3.14159265358979323846, V = L * L * L;
     for (int a = -kmax; a <= kmax; ++a)
       for (int b = -kmax; b <= kmax; ++b)
@@ -233,6 +347,11 @@ int nb_launch_accel_ewald(nb_ctx* c, int dtype, const void* x, const void* y, co
           const int n2 = a * a + b * b + d * d;
           if (n2 == 0 || n2 > kmax * kmax) continue;
           if (!(a > 0 || (a == 0 && (b > 0 || (b == 0 && d > 0))))) continue;
+          const int q = (int)(kv.size() / 4);
+          if (rows.empty() || rows[rows.size() - 2] + rows.back() != q || kv[4 * (q - 1)] != 2 * PI * a / L || kv[4 * (q - 1) + 1] != 2 * PI * b / L) {
+            rows.push_back(q); rows.push_back(0);
+          }
+          rows.back() += 1;
           const double kx = 2 * PI * a / L, ky = 2 * PI * b / L, kz = 2 * PI * d / L, k2 = kx * kx + ky * ky + kz * kz;
           kv.push_back(kx); kv.push_back(ky); kv.push_back(kz);
           kv.push_back(2.0 * (4.0 * PI / V) * std::exp(-k2 / (4.0 * alpha * alpha)) / k2);
@@ -240,6 +359,10 @@ int nb_launch_accel_ewald(nb_ctx* c, int dtype, const void* x, const void* y, co
     NB_HIP(c, hipStreamSynchronize(c->stream));
     if (e.kvec) { NB_HIP(c, hipFree(e.kvec)); e.kvec = nullptr; }
     if (e.sk) { NB_HIP(c, hipFree(e.sk)); e.sk = nullptr; }
+    if (e.rows) { NB_HIP(c, hipFree(e.rows)); e.rows = nullptr; }
+    e.nrows = (int)(rows.size() / 2);
+    NB_HIP(c, hipMalloc((void**)&e.rows, rows.size() * sizeof(int)));
+    NB_HIP(c, hipMemcpy(e.rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
     e.nk = (int)(kv.size() / 4);
     NB_HIP(c, hipMalloc((void**)&e.kvec, kv.size() * sizeof(double)));
     NB_HIP(c, hipMalloc((void**)&e.sk, 2 * (size_t)e.nk * sizeof(double)));
@@ -247,7 +370,6 @@ int nb_launch_accel_ewald(nb_ctx* c, int dtype, const void* x, const void* y, co
     e.L = L; e.alphaL = alphaL; e.kmax = kmax;
   }
   const int nb = (int)((n + BLOCK - 1) / BLOCK);
-  const size_t lds = 6 * 256 * sizeof(double);
   // A splitting parameter large enough that the real-space terms have died out (alpha r = 3.3: 7e-5 of the pair force) within a
   // third of the box turns the all-pairs minimum-image sum into the cell-list pair sum of mesh.hip: 27 of nc^3 cells per sink.
   const double rcut = 3.3 / alpha;
@@ -258,19 +380,10 @@ int nb_launch_accel_ewald(nb_ctx* c, int dtype, const void* x, const void* y, co
     NB_HIP(c, hipMemsetAsync(az, 0, (size_t)n * eb, c->stream));
     int rc = nb_launch_short_range(c, dtype, x, y, z, m, n, L, alpha, rcut, eps2, G, ax, ay, az);
     if (rc) return rc;
-    if (dtype == NB_F32) {
-      ewald_sk_kernel<float><<<e.nk, BLOCK, 0, c->stream>>>((const float*)x, (const float*)y, (const float*)z, (const float*)m, (int)n, e.kvec, e.sk);
-      NB_HIP(c, hipGetLastError());
-      ewald_recip_kernel<float><<<nb, BLOCK, lds, c->stream>>>((const float*)x, (const float*)y, (const float*)z, (int)n, e.kvec, e.sk, e.nk, G,
-                                                               (float*)ax, (float*)ay, (float*)az);
-    } else {
-      ewald_sk_kernel<double><<<e.nk, BLOCK, 0, c->stream>>>((const double*)x, (const double*)y, (const double*)z, (const double*)m, (int)n, e.kvec, e.sk);
-      NB_HIP(c, hipGetLastError());
-      ewald_recip_kernel<double><<<nb, BLOCK, lds, c->stream>>>((const double*)x, (const double*)y, (const double*)z, (int)n, e.kvec, e.sk, e.nk, G,
-                                                                (double*)ax, (double*)ay, (double*)az);
-    }
-    NB_HIP(c, hipGetLastError());
-    return NB_OK;
+    if (dtype == NB_F32)
+      return launch_recip<float>(c, e, (const float*)x, (const float*)y, (const float*)z, (const float*)m, n, L, G, (float*)ax, (float*)ay, (float*)az);
+    return launch_recip<double>(c, e, (const double*)x, (const double*)y, (const double*)z, (const double*)m, n, L, G, (double*)ax, (double*)ay,
+                                (double*)az);
   }
   if (dtype == NB_F32) {
     const float *fx = (const float*)x, *fy = (const float*)y, *fz = (const float*)z, *fm = (const float*)m;
@@ -284,17 +397,11 @@ int nb_launch_accel_ewald(nb_ctx* c, int dtype, const void* x, const void* y, co
     ewald_real_f32_kernel<<<nb, BLOCK, 0, c->stream>>>(fx, fy, fz, fm, (int)n, (float)L, (float)(ETAB / smax), (float)eps2, (float)G,
                                                        e.table, (float*)ax, (float*)ay, (float*)az);
     NB_HIP(c, hipGetLastError());
-    ewald_sk_kernel<float><<<e.nk, BLOCK, 0, c->stream>>>(fx, fy, fz, fm, (int)n, e.kvec, e.sk);
-    NB_HIP(c, hipGetLastError());
-    ewald_recip_kernel<float><<<nb, BLOCK, lds, c->stream>>>(fx, fy, fz, (int)n, e.kvec, e.sk, e.nk, G, (float*)ax, (float*)ay, (float*)az);
+    return launch_recip<float>(c, e, fx, fy, fz, fm, n, L, G, (float*)ax, (float*)ay, (float*)az);
   } else {
     const double *dx = (const double*)x, *dy = (const double*)y, *dz = (const double*)z, *dm = (const double*)m;
     ewald_real_kernel<<<nb, BLOCK, 0, c->stream>>>(dx, dy, dz, dm, (int)n, L, alpha, eps2, G, (double*)ax, (double*)ay, (double*)az);
     NB_HIP(c, hipGetLastError());
-    ewald_sk_kernel<double><<<e.nk, BLOCK, 0, c->stream>>>(dx, dy, dz, dm, (int)n, e.kvec, e.sk);
-    NB_HIP(c, hipGetLastError());
-    ewald_recip_kernel<double><<<nb, BLOCK, lds, c->stream>>>(dx, dy, dz, (int)n, e.kvec, e.sk, e.nk, G, (double*)ax, (double*)ay, (double*)az);
+    return launch_recip<double>(c, e, dx, dy, dz, dm, n, L, G, (double*)ax, (double*)ay, (double*)az);
   }
-  NB_HIP(c, hipGetLastError());
-  return NB_OK;
 }

@@ -3,7 +3,7 @@ spectrum of the thesis' `pp` run (64^3 particles, 500 Mpc periodic box, a = 0.02
 = PPPMP3M/PP/powerspec/powerspec_a=1.00). The same configuration is run here (Zel'dovich ICs from the table's own linear column,
 comoving KDK, fp32 Ewald forces) with a reduced step count and its P(k), binned like CONCEPT's table, must agree with the table
 within realisation scatter. The full 400-step run is tools/run_pp_reference.py (profiles/r01_pp_reference_configuration_64cubed_fp32.txt:
-ratio 0.94-1.01 over bins 6-16, 14 s instead of CONCEPT's 257 257 s)."""
+ratio 0.94-1.01 over bins 6-16, 6.4 s instead of CONCEPT's 257 257 s)."""
 from pathlib import Path
 
 import numpy as np

@@ -132,4 +132,4 @@ def test_ewald_cell_list_real_space_sum(clustered, dtype):
         assert np.abs(got - ref).max() < 3e-5 * np.abs(ref).max()
     with nb.Engine(n, np.float32) as e:                                  # kmax range of the API
         with pytest.raises(RuntimeError, match="kmax"):
-            e.set_periodic(L, 13.2, 25)
+            e.set_periodic(L, 13.2, 32)

@@ -20,7 +20,7 @@ pos = rng.uniform(0, L, (n, 3)); pos[: n // 3] = np.mod(50 + 3 * rng.normal(size
 m = rng.uniform(0.5, 1.5, n)
 ref, _ = accel(pos, m, L, np.float64, 7.5, 13, 0.05)
 scale = np.sqrt((ref ** 2).sum(1).mean())
-for aL, kmax in ((6.2, 7), (10.0, 12), (13.2, 15), (13.2, 16), (16.5, 19), (16.5, 20)):
+for aL, kmax in ((6.2, 7), (13.2, 15), (16.5, 19), (19.8, 23), (23.1, 27), (26.4, 30)):
     a, _ = accel(pos, m, L, np.float32, aL, kmax, 0.05)
     e = np.linalg.norm(a - ref, axis=1)
     print(json.dumps({"alpha_L": aL, "kmax": kmax, "rms_err_over_rms_force": float(np.sqrt((e ** 2).mean()) / scale), "max_err_over_rms_force": float(e.max() / scale)}), flush=True)
@@ -28,6 +28,6 @@ n_side = 64
 g = (np.arange(n_side) + 0.25) * (500.0 / n_side)
 q = np.array(np.meshgrid(g, g, g, indexing="ij")).reshape(3, -1).T + rng.normal(scale=2.0, size=(n_side ** 3, 3))
 q = np.mod(q, 500.0); mm = np.ones(len(q))
-for aL, kmax in ((6.2, 7), (13.2, 15), (16.5, 19)):
+for aL, kmax in ((6.2, 7), (13.2, 15), (16.5, 19), (19.8, 23), (23.1, 27), (26.4, 30)):
     _, t = accel(q, mm, 500.0, np.float32, aL, kmax, 0.23, reps=5)
     print(json.dumps({"n": len(q), "alpha_L": aL, "kmax": kmax, "ms_per_force_evaluation": 1e3 * t}), flush=True)
