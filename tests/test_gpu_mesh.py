@@ -63,7 +63,7 @@ def test_p3m_parts_match_oracle(dtype, clustered):
 
 def test_p3m_agrees_with_ewald_solver():
     """The two periodic solvers of the library against each other and against the Ewald oracle."""
-    L, n, eps = 100.0, 6000, 0.3
+    L, n, eps = 100.0, 3200, 0.3
     pos, m = _cloud(n, L, 3)
     s = nb.State(pos, np.zeros_like(pos), m)
     with nb.Engine(n, np.float64) as e:
