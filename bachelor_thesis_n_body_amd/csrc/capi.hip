@@ -226,7 +226,7 @@ static int refresh_acc(nb_ctx* c, double eps, double G, double* phi = nullptr) {
     double* s = reinterpret_cast<double*>(c->state);
     const size_t n = (size_t)c->n;
     rc = nb_launch_accel_f64(c, s, s + n, s + 2 * n, c->n, s, s + n, s + 2 * n, s + 3 * n, c->n, eps * eps, G,
-                             s + 7 * n, s + 8 * n, s + 9 * n, 0, phi);
+                             s + 7 * n, s + 8 * n, s + 9 * n, c->uniform_mass ? NB_UNIFORM_MASS : 0, phi);
   }
   if (rc) return rc;
   c->acc_valid = true; c->acc_eps = eps; c->acc_G = G;
