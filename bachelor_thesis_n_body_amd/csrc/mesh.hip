@@ -29,6 +29,7 @@
 // minimum image.                                                                                    [VALU bound]
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
@@ -55,7 +56,6 @@ struct nb_mesh_state {
 
 namespace {
 
-constexpr int SRB = 128;   // short-range block = sink chunk = source tile
 constexpr int SUBBITS = 6; // sub-cell bits below the cell index in the sort key
 
 struct d4 { double x, y, z, w; };
@@ -386,38 +386,53 @@ __device__ inline double sr_factor(double r2, double eps2, double alpha, double 
   return soft - lng;
 }
 
-// One block per chunk of <= SRB consecutive sorted particles of one ROW of cells (fixed cx, cy; cells consecutive in z are
+// One block (one wave) per chunk of <= 64*KS consecutive sorted particles of one ROW of cells (fixed cx, cy; cells consecutive in z are
 // consecutive in memory). Sparse cells are packed together into full blocks; a dense cell is split into several chunks.
 // The sinks span cells lo..hi of the row; sources are the unwrapped cells lo-1..hi+1 of the 9 neighbouring rows, walked as
 // contiguous memory segments (split where the periodic image changes). Images out of reach contribute nothing through the
 // cut-off test, so every sink sees each of its 27 neighbour-cell images exactly once.
-template <typename T, typename V4>
-__global__ void __launch_bounds__(SRB)
+constexpr int SRW = 4;      // waves (= independent chunks) per block; they share only the look-up table
+
+template <typename T, typename V4, int KS>
+__global__ void __launch_bounds__(64 * SRW)
 short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ keys_s, const int* __restrict__ cell_start,
                    const int* __restrict__ chunk_off, int nrows, int nc, T L, T alpha, T rcut2, T eps2, double G,
                    const uint32_t* __restrict__ idx_s, const float* __restrict__ table, T* __restrict__ ax, T* __restrict__ ay,
                    T* __restrict__ az) {
-  constexpr bool TABLE = sizeof(T) == 4;
-  __shared__ V4 tile[SRB];
+  // One WAVE per chunk of 64*KS consecutive sorted particles; lane l owns particles l, l+64, ... of the chunk, so each of the KS
+  // sink sets is a compact 64-particle blob with its own cut-off vote, while one LDS broadcast of a source serves all KS sets.
+  // SRW independent waves share a block only for the look-up table. (PMC of the one-sink-per-lane version: LDS 74 % busy — tile
+  // broadcasts and random-address table reads — VALU 27 %; two sinks per lane: 256^3 P3M 43 -> 37 ms. A degree-10 polynomial
+  // instead of the table was tried and measured slower: its serial Horner chain costs more than the look-up.)
+  constexpr bool TABLE = sizeof(T) == 4;        // fp32: long-range complement from the LDS table; fp64: exact erf/exp
+  constexpr int CH = 64 * KS;
+  __shared__ V4 tiles[SRW][64];
   __shared__ float tab[TABLE ? TABN + 2 : 1];
+  if (TABLE) {                                  // the only block-wide step: every wave takes part before any may leave
+    for (int t = threadIdx.x; t < TABN + 2; t += 64 * SRW) tab[t] = table[t];
+    __syncthreads();
+  }
+  V4* tile = tiles[threadIdx.x >> 6];           // private to the wave: wave-scope fences order its writes and reads
   const int total = chunk_off[nrows];
-  const int w = blockIdx.x;
+  const int w = blockIdx.x * SRW + (int)(threadIdx.x >> 6);
   if (w >= total) return;                       // the grid is an upper bound on the number of chunks
-  // row = last r with chunk_off[r] <= w  (block-uniform binary search)
+  // row = last r with chunk_off[r] <= w  (wave-uniform binary search)
   int lo_r = 0, hi_r = nrows;
   while (hi_r - lo_r > 1) { const int mid = (lo_r + hi_r) >> 1; if (chunk_off[mid] <= w) lo_r = mid; else hi_r = mid; }
   const int row = lo_r, chunk = w - chunk_off[row];
   const int cx = row / nc, cy = row % nc;
   const int r1 = cell_start[(row + 1) * nc];
-  const int i_first = cell_start[row * nc] + chunk * SRB, i_last = min(r1, i_first + SRB) - 1;
+  const int i_first = cell_start[row * nc] + chunk * CH, i_last = min(r1, i_first + CH) - 1;
   const int zlo = (int)((keys_s[i_first] >> SUBBITS) % (uint32_t)nc), zhi = (int)((keys_s[i_last] >> SUBBITS) % (uint32_t)nc);
-  const int i = i_first + (int)threadIdx.x;
-  const bool live = i <= i_last;
-  const V4 me = sorted[live ? i : i_last];
+  const int lane = threadIdx.x & 63;
+  V4 me[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) me[k] = sorted[min(i_first + k * 64 + lane, i_last)];
   const T c2 = (T)2 * alpha * (T)0.5641895835477563, a2l = 0;
-  if (TABLE) for (int t = threadIdx.x; t < TABN + 2; t += SRB) tab[t] = table[t];     // first use is behind the tile barrier
   const float tscale = TABLE ? (float)TABN / (float)rcut2 : 0.f;
-  double tx = 0.0, ty = 0.0, tz = 0.0;
+  double tx[KS], ty[KS], tz[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) { tx[k] = 0.0; ty[k] = 0.0; tz[k] = 0.0; }
   for (int nb = 0; nb < 9; ++nb) {
     int qx = cx + nb / 3 - 1, qy = cy + nb % 3 - 1;
     T shx = 0, shy = 0;                         // periodic image of the whole neighbour row
@@ -430,48 +445,58 @@ short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ k
       const T shz = (T)img * L;
       const int b0 = cell_start[qbase + (a - img * nc)], b1 = cell_start[qbase + (b - img * nc) + 1];
       a = b + 1;
-      for (int j0 = b0; j0 < b1; j0 += SRB) {
-        __syncthreads();
-        const int j = j0 + (int)threadIdx.x;
+      for (int j0 = b0; j0 < b1; j0 += 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous tile has been consumed
+        const int j = j0 + lane;
         if (j < b1) {
           V4 s = sorted[j];
           s.x += shx; s.y += shy; s.z += shz;
-          tile[threadIdx.x] = s;
+          tile[lane] = s;
         }
-        __syncthreads();
-        const int cnt = min(SRB, b1 - j0);
-        T fx = 0, fy = 0, fz = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // LDS serves a wave's accesses in order: the tile is visible
+        const int cnt = min(64, b1 - j0);
+        T fx[KS], fy[KS], fz[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) { fx[k] = 0; fy[k] = 0; fz[k] = 0; }
         for (int e = 0; e < cnt; ++e) {
-          const V4 s = tile[e];                   // wave-uniform address: LDS broadcast
-          const T dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
-          const T r2 = dx * dx + dy * dy + dz * dz;
-          // wave-uniform branch: the 64 sinks of a wave are a compact blob (sub-cell sort), most sources of the walked
-          // cells are out of reach of all of them and cost only the distance test
-          if (__builtin_amdgcn_ballot_w64(r2 < rcut2) != 0) {
-            T pair;
-            if constexpr (TABLE) {
-              const float t = (float)r2 * tscale;
-              const int it = min((int)t, TABN);                  // lanes beyond the cut-off are masked below
-              const float fr = t - (float)it;
-              const float t0 = tab[it], t1 = tab[it + 1];
-              const float sinv = __builtin_amdgcn_rsqf((float)r2 + (float)eps2);
-              const float soft = r2 > (T)0 ? sinv * sinv * sinv : 0.f;
-              pair = soft - fmaf(fr, t1 - t0, t0);
-            } else {
-              pair = sr_factor(r2, eps2, alpha, c2, a2l);
+          const V4 s = tile[e];                   // wave-uniform address: one LDS broadcast for all KS sink sets
+#pragma unroll
+          for (int k = 0; k < KS; ++k) {
+            const T dx = s.x - me[k].x, dy = s.y - me[k].y, dz = s.z - me[k].z;
+            const T r2 = dx * dx + dy * dy + dz * dz;
+            // wave-uniform branch: the 64 sinks of a set are a compact blob (sub-cell sort), most sources of the walked cells
+            // are out of reach of all of them and cost only the distance test
+            if (__builtin_amdgcn_ballot_w64(r2 < rcut2) != 0) {
+              T pair;
+              if constexpr (TABLE) {
+                const float t = (float)r2 * tscale;
+                const int it = min((int)t, TABN);                  // lanes beyond the cut-off are masked below
+                const float fr = t - (float)it;
+                const float t0 = tab[it], t1 = tab[it + 1];
+                const float sinv = __builtin_amdgcn_rsqf((float)r2 + (float)eps2);
+                const float soft = r2 > (T)0 ? sinv * sinv * sinv : 0.f;
+                pair = soft - fmaf(fr, t1 - t0, t0);
+              } else {
+                pair = sr_factor(r2, eps2, alpha, c2, a2l);
+              }
+              T f = s.w * pair;
+              f = r2 < rcut2 ? f : (T)0;
+              fx[k] += f * dx; fy[k] += f * dy; fz[k] += f * dz;
             }
-            T f = s.w * pair;
-            f = r2 < rcut2 ? f : (T)0;
-            fx += f * dx; fy += f * dy; fz += f * dz;
           }
         }
-        tx += (double)fx; ty += (double)fy; tz += (double)fz;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) { tx[k] += (double)fx[k]; ty[k] += (double)fy[k]; tz[k] += (double)fz[k]; }
       }
     }
   }
-  if (live) {
-    const uint32_t o = idx_s[i];
-    ax[o] += (T)(G * tx); ay[o] += (T)(G * ty); az[o] += (T)(G * tz);
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int i = i_first + k * 64 + lane;
+    if (i <= i_last) {
+      const uint32_t o = idx_s[i];
+      ax[o] += (T)(G * tx[k]); ay[o] += (T)(G * ty[k]); az[o] += (T)(G * tz[k]);
+    }
   }
 }
 
@@ -550,20 +575,26 @@ int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z,
   cell_start_kernel<<<(int)((n + 1 + 255) / 256), 256, 0, st>>>(s.keys_s, n, ncell3, SUBBITS, s.cell_start);
   NB_HIP(c, hipGetLastError());
   const int nrows = nc * nc;
-  chunk_count_kernel<<<(nrows + 1 + 255) / 256, 256, 0, st>>>(s.cell_start, nrows, nc, SRB, s.chunk_cnt);
+  static const int ks_env = getenv("NB_SR_KS") ? atoi(getenv("NB_SR_KS")) : 0;
+  // sinks per lane (chunk = 64 * ks particles): 2 halves the LDS broadcasts per pair; with very full cells (the Ewald cut-off:
+  // thousands of particles per cell, hardly any source out of reach of a 64-sink blob) 1 measured 6 % faster
+  const int ks = (ks_env == 1 || ks_env == 2 || ks_env == 4) ? ks_env : (n / ncell3 >= 1024 ? 1 : 2);
+  const int chunk = 64 * ks;
+  chunk_count_kernel<<<(nrows + 1 + 255) / 256, 256, 0, st>>>(s.cell_start, nrows, nc, chunk, s.chunk_cnt);
   NB_HIP(c, hipGetLastError());
   tb = s.tmp_bytes;
   NB_HIP(c, rocprim::exclusive_scan(s.tmp, tb, s.chunk_cnt, s.chunk_off, 0, (size_t)nrows + 1, rocprim::plus<int>(), st));
-  const int64_t max_chunks = (int64_t)nrows + n / SRB + 1;      // sum_r ceil(n_r / SRB) <= nrows + n / SRB
+  const int64_t max_chunks = (int64_t)nrows + n / chunk + 1;    // sum_r ceil(n_r / chunk) <= nrows + n / chunk
   if (sizeof(T) == 4 && (!s.table || s.table_alpha != alpha || s.table_rcut != rcut)) {
     if (!s.table) NB_HIP(c, hipMalloc((void**)&s.table, (TABN + 2) * sizeof(float)));
     sr_table_kernel<<<(TABN + 2 + 255) / 256, 256, 0, st>>>(s.table, alpha, rcut * rcut);
     NB_HIP(c, hipGetLastError());
     s.table_alpha = alpha; s.table_rcut = rcut;
   }
-  short_range_kernel<T, V4><<<(unsigned)max_chunks, SRB, 0, st>>>((const V4*)s.sorted, s.keys_s, s.cell_start, s.chunk_off, nrows, nc,
-                                                                   (T)L, (T)alpha, (T)(rcut * rcut), (T)eps2, G, s.idx_s, s.table,
-                                                                   ax, ay, az);
+#define NB_SR(K) short_range_kernel<T, V4, K><<<(unsigned)((max_chunks + SRW - 1) / SRW), 64 * SRW, 0, st>>>((const V4*)s.sorted, s.keys_s, \
+    s.cell_start, s.chunk_off, nrows, nc, (T)L, (T)alpha, (T)(rcut * rcut), (T)eps2, G, s.idx_s, s.table, ax, ay, az)
+  if (ks == 1) NB_SR(1); else if (ks == 2) NB_SR(2); else NB_SR(4);
+#undef NB_SR
   NB_HIP(c, hipGetLastError());
   return NB_OK;
 }
