@@ -51,29 +51,50 @@ def _load_pk_table(args, s) -> np.ndarray:
 
 
 def _run_cosmological(args, p, s) -> int:
-    """CONCEPT-like run: Zel'dovich ICs at a_begin from the linear P(k) table (at a = 1), comoving KDK with periodic Ewald
-    forces up to the last requested scale factor, snapshot (+ power spectrum) at every requested output time."""
+    """CONCEPT-like run: Zel'dovich / 2LPT ICs at a_begin from the linear P(k) table (at a = 1) — or a snapshot to resume from —
+    comoving KDK with periodic 'pp' / 'pm' / 'p3m' forces up to the last requested scale factor, snapshot and power spectrum at
+    their requested output times."""
     from . import cosmo, field, snapshot
     L = s["boxsize"]
-    n_side = round(s["N"] ** (1.0 / 3.0))
-    if n_side ** 3 != s["N"] or not args.pk_table or not p.get("H0"):
-        print("concept: --cosmological needs N = n^3, --pk-table (linear P(k) at a = 1) and H0/Ωb/Ωcdm in the parameter file", file=sys.stderr)
+    if not p.get("H0"):
+        print("concept: --cosmological needs H0/Ωb/Ωcdm in the parameter file", file=sys.stderr)
         return 2
     h = float(p["H0"]) / (100 * _params.UNITS["km"] / _params.UNITS["s"])
     c = cosmo.Cosmology(float(p["H0"]), float(p["Ωb"]) + float(p["Ωcdm"]), (2.473e-5 * (1.0 + 0.2271 * 3.046)) / h ** 2)
     seeds = s["random_seeds"]
-    a0 = s["a_begin"]
-    if s["lpt"] not in (1, 2):
-        print(f"concept: realization_options['LPT'] = {s['lpt']}: orders 1 and 2 are implemented", file=sys.stderr)
-        return 3
-    table = _load_pk_table(args, s)
-    pos, vel, noise_power = cosmo.zeldovich_ics(table, n_side, L, c, a0, int(seeds.get("primordial amplitudes", 0)),
-                                                int(seeds.get("primordial phases", 1)), lpt=s["lpt"], return_noise_power=True)
-    mass = c.particle_mass(L, n_side ** 3)
+    ic_file = args.ic or s["ic_file"]
+    table = _load_pk_table(args, s) if args.pk_table else None
+    if ic_file:
+        # resume from a CONCEPT-layout snapshot (`initial_conditions = '<path>'`): positions, comoving momenta a^2 m dx/dt and
+        # the scale factor it was written at (root attribute 'a', as in the reference's own snapshots)
+        pos = snapshot.read_positions(ic_file)
+        attrs, comp = snapshot.read_attrs(ic_file), snapshot.read_attrs(ic_file, "components/matter")
+        vel = snapshot.read_momenta(ic_file) / float(comp["mass"])
+        a0 = float(attrs.get("a", s["a_begin"]))
+        n_side = round(pos.shape[0] ** (1.0 / 3.0))
+        noise_power = None
+        if float(attrs.get("boxsize", L)) != L or n_side ** 3 != pos.shape[0]:
+            print("concept: the snapshot's boxsize / particle number does not fit the parameter file", file=sys.stderr)
+            return 2
+    else:
+        n_side = round(s["N"] ** (1.0 / 3.0))
+        if n_side ** 3 != s["N"] or table is None:
+            print("concept: --cosmological needs N = n^3 and --pk-table (linear P(k) at a = 1) to generate initial conditions", file=sys.stderr)
+            return 2
+        a0 = s["a_begin"]
+        if s["lpt"] not in (1, 2):
+            print(f"concept: realization_options['LPT'] = {s['lpt']}: orders 1 and 2 are implemented", file=sys.stderr)
+            return 3
+        pos, vel, noise_power = cosmo.zeldovich_ics(table, n_side, L, c, a0, int(seeds.get("primordial amplitudes", 0)),
+                                                    int(seeds.get("primordial phases", 1)), lpt=s["lpt"], return_noise_power=True)
+    mass = float(comp["mass"]) if ic_file else c.particle_mass(L, n_side ** 3)
     snap_t = set(t for t in (s["snapshot_times"] or [1.0]) if t > a0)
     # power spectra: at `output_times['powerspec']` when given (SnapVsPK/Uncertain.param:13-16), else with every snapshot
     ps_t = set(t for t in (s["powerspec_times"] or (snap_t if s["powerspec_dir"] else [])) if t > a0)
     outs = sorted(snap_t | ps_t)
+    if not outs:
+        print(f"concept: nothing to do: every output time is at or before the starting scale factor a = {a0:g}", file=sys.stderr)
+        return 0
     out = Path(s["snapshot_dir"])
     out.mkdir(parents=True, exist_ok=True)
     nsteps = args.steps if args.steps > 0 else 400
@@ -86,7 +107,7 @@ def _run_cosmological(args, p, s) -> int:
                                 scale_cells=s["mesh"]["scale"], range_scales=s["mesh"]["range"])
         if a1 in snap_t:
             snapshot.write_snapshot(str(out / f"snapshot_a={a1:.2f}.hdf5"), pos, vel * mass, L, mass=mass,
-                                    extra_attrs={"a": float(a1), "H0": float(p["H0"])})
+                                    extra_attrs={"a": float(a1), "H0": float(p["H0"]), "Ωb": float(p["Ωb"]), "Ωcdm": float(p["Ωcdm"])})
         if a1 in ps_t:
             pdir = Path(s["powerspec_dir"] or out.parent / "powerspec"); pdir.mkdir(parents=True, exist_ok=True)
             kk, cnt, pk, pcorr, plin = cosmo.concept_power_table(pos, L, n_side, table, c.growth(a1)[0], noise_power)

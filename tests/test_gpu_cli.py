@@ -109,3 +109,25 @@ def test_cli_power_spectrum_file_has_concepts_columns(tmp_path):
     low = kk < 0.5 * np.pi * 16 / 500.0
     assert np.abs(P_corr[low] / P_lin[low] - 1).max() < 0.1
     assert np.abs(P_corr[low] / P_lin[low] - 1).mean() < 0.5 * np.abs(P[low] / P_lin[low] - 1).mean()
+
+
+def test_cli_cosmological_run_resumes_from_its_own_snapshot(tmp_path):
+    """`initial_conditions = '<snapshot>'` (CONCEPT's way to resume) in the comoving mode: a run written at a = 0.5 and continued to
+    a = 1 ends where the uninterrupted run with outputs at both times ends, bit for bit (same step schedule)."""
+    k = np.logspace(-3, 1, 200)
+    np.savetxt(tmp_path / "pk.txt", np.column_stack([k, 2.0e4 * (k / 0.02) / (1 + (k / 0.02) ** 2) ** 1.6]))
+    common = ["--cosmological", "--pk-table", str(tmp_path / "pk.txt"), "--dtype", "f32",
+              "-c", "potential_options = {'gridsize': 24, 'interlace': {'gravity': {'p3m': (True, True)}}}"]
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    assert concept.main(["-p", str(_write(one, "p3m")), "--steps", "40", "-c", "output_times = {'snapshot': [0.5, 1.0]}"] + common) == 0
+    whole = {p.name: p for p in (one / "output").rglob("snapshot_a=*.hdf5")}
+    n1 = round(40 * np.log(0.5 / 0.02) / np.log(1.0 / 0.02))
+    f2 = _write(two, "p3m")
+    assert concept.main(["-p", str(f2), "--steps", str(40 - n1), "--ic", str(whole["snapshot_a=0.50.hdf5"]),
+                         "-c", "output_times = {'snapshot': [0.5, 1.0]}"] + common) == 0          # a = 0.5 is skipped: already there
+    resumed = list((two / "output").rglob("snapshot_a=*.hdf5"))
+    assert [p.name for p in resumed] == ["snapshot_a=1.00.hdf5"]
+    np.testing.assert_array_equal(sn.read_positions(str(resumed[0])), sn.read_positions(str(whole["snapshot_a=1.00.hdf5"])))
+    np.testing.assert_array_equal(sn.read_momenta(str(resumed[0])), sn.read_momenta(str(whole["snapshot_a=1.00.hdf5"])))
+    assert sn.read_attrs(str(resumed[0]))["Ωcdm"] > 0.2
