@@ -64,6 +64,14 @@ class Engine:
     def handle(self) -> C.c_void_p:
         return self._ctx
 
+    def kdk_run(self, kick1, drift, kick2, eps: float, G: float = 1.0) -> None:
+        """len(kick1) generalised KDK steps enqueued back to back (one host synchronisation for the whole run)."""
+        k1, d, k2 = (np.ascontiguousarray(a, np.float64) for a in (kick1, drift, kick2))
+        if not (k1.shape == d.shape == k2.shape and k1.ndim == 1):
+            raise ValueError("kick1, drift, kick2 must be 1-D arrays of equal length")
+        _lib.check(self._ctx, self._lib.nb_kdk_run(self._ctx, k1.size, k1.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                                                   k2.ctypes.data_as(C.c_void_p), eps, G), "nb_kdk_run")
+
     def set_stream(self, hip_stream: int) -> None:
         _lib.check(self._ctx, self._lib.nb_set_stream(self._ctx, C.c_void_p(hip_stream)), "nb_set_stream")
 

@@ -201,10 +201,15 @@ def run_pp(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: flo
             e.set_mesh(gravity, boxsize, int(ngrid) if ngrid else (cb if gravity == "pm" else 2 * cb), scale_cells, range_scales,
                        interlace)
         e.set_state(State(np.asarray(pos, dtype), np.asarray(vel, dtype), np.full(n, mass, dtype)))
-        for a0, a1 in zip(edges[:-1], edges[1:]):
-            am = np.sqrt(a0 * a1)
-            e.kdk_step(cosmo.kick_factor(a0, am), cosmo.drift_factor(a0, a1), cosmo.kick_factor(am, a1), eps, _params.G_NEWTON)
-            if callback is not None:
+        if callback is None:                       # the whole run as one call: no host round trip between the steps
+            mids = np.sqrt(edges[:-1] * edges[1:])
+            e.kdk_run([cosmo.kick_factor(a0, am) for a0, am in zip(edges[:-1], mids)],
+                      [cosmo.drift_factor(a0, a1) for a0, a1 in zip(edges[:-1], edges[1:])],
+                      [cosmo.kick_factor(am, a1) for am, a1 in zip(mids, edges[1:])], eps, _params.G_NEWTON)
+        else:
+            for a0, a1 in zip(edges[:-1], edges[1:]):
+                am = np.sqrt(a0 * a1)
+                e.kdk_step(cosmo.kick_factor(a0, am), cosmo.drift_factor(a0, a1), cosmo.kick_factor(am, a1), eps, _params.G_NEWTON)
                 callback(float(a1), e)
         st = e.get_state()
     return st.pos.astype(np.float64), st.vel.astype(np.float64)

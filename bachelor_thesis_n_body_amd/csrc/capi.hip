@@ -310,22 +310,39 @@ int nb_step(nb_ctx* c, double dt, int64_t nsteps, double eps, double G) {
   return nb_bh_check(c);
 }
 
+static int kdk_enqueue(nb_ctx* c, double kick1, double drift, double kick2, double eps, double G) {
+  const size_t b = (size_t)c->n * esize(c->dtype);
+  char* s = reinterpret_cast<char*>(c->state);
+  void *x = s, *y = s + b, *z = s + 2 * b, *vx = s + 4 * b, *vy = s + 5 * b, *vz = s + 6 * b;
+  void *ax = s + 7 * b, *ay = s + 8 * b, *az = s + 9 * b;
+  int rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, kick1); if (rc) return rc;
+  rc = nb_launch_drift(c, c->dtype, x, y, z, vx, vy, vz, c->n, drift); if (rc) return rc;
+  if (c->solver >= NB_SOLVER_EWALD) { rc = nb_launch_wrap(c, c->dtype, x, y, z, c->n, c->box); if (rc) return rc; }
+  rc = refresh_acc(c, eps, G); if (rc) return rc;
+  return nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, kick2);
+}
+
 int nb_kdk_step(nb_ctx* c, double kick1, double drift, double kick2, double eps, double G) {
   if (!c) return NB_ERR_ARG;
   if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_kdk_step: call nb_set_state first");
   if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_kdk_step: eps must be >= 0");
   int rc = use_device(c); if (rc) return rc;
   if (!c->acc_valid || c->acc_eps != eps || c->acc_G != G) { rc = refresh_acc(c, eps, G); if (rc) return rc; }
-  const size_t b = (size_t)c->n * esize(c->dtype);
-  char* s = reinterpret_cast<char*>(c->state);
-  void *x = s, *y = s + b, *z = s + 2 * b, *vx = s + 4 * b, *vy = s + 5 * b, *vz = s + 6 * b;
-  void *ax = s + 7 * b, *ay = s + 8 * b, *az = s + 9 * b;
-  rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, kick1); if (rc) return rc;
-  rc = nb_launch_drift(c, c->dtype, x, y, z, vx, vy, vz, c->n, drift); if (rc) return rc;
-  if (c->solver >= NB_SOLVER_EWALD) { rc = nb_launch_wrap(c, c->dtype, x, y, z, c->n, c->box); if (rc) return rc; }
-  rc = refresh_acc(c, eps, G); if (rc) return rc;
-  rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, kick2); if (rc) return rc;
+  rc = kdk_enqueue(c, kick1, drift, kick2, eps, G); if (rc) return rc;
   NB_HIP(c, hipStreamSynchronize(c->stream));
+  return nb_bh_check(c);
+}
+
+int nb_kdk_run(nb_ctx* c, int64_t nsteps, const double* kick1, const double* drift, const double* kick2, double eps, double G) {
+  if (!c) return NB_ERR_ARG;
+  if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_kdk_run: call nb_set_state first");
+  if (nsteps < 0 || (nsteps > 0 && (!kick1 || !drift || !kick2))) return nb_fail(c, NB_ERR_ARG, "nb_kdk_run: bad step arrays");
+  if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_kdk_run: eps must be >= 0");
+  if (nsteps == 0) return NB_OK;
+  int rc = use_device(c); if (rc) return rc;
+  if (!c->acc_valid || c->acc_eps != eps || c->acc_G != G) { rc = refresh_acc(c, eps, G); if (rc) return rc; }
+  for (int64_t k = 0; k < nsteps; ++k) { rc = kdk_enqueue(c, kick1[k], drift[k], kick2[k], eps, G); if (rc) return rc; }
+  NB_HIP(c, hipStreamSynchronize(c->stream));       // the only host round trip of the run
   return nb_bh_check(c);
 }
 

@@ -93,6 +93,9 @@ int nb_set_mesh(nb_ctx* ctx, int solver, double boxsize, int ngrid, double scale
 /* one generalised KDK step: v += a*kick1; x += v*drift; a = a(x); v += a*kick2 — with kick = integral dt/a and
  * drift = integral dt/a^2 this is the comoving leapfrog of a cosmological run (v = canonical momentum per unit mass) */
 int nb_kdk_step(nb_ctx* ctx, double kick1, double drift, double kick2, double eps, double G);
+/* nsteps generalised KDK steps with per-step factors (host arrays of nsteps doubles), enqueued back to back: one host
+ * synchronisation for the whole run — a comoving run from a_begin to an output time is one call */
+int nb_kdk_run(nb_ctx* ctx, int64_t nsteps, const double* kick1, const double* drift, const double* kick2, double eps, double G);
 
 /* ---- host-pointer surface: the drop-in compute_forces()/step()/energy() (SURVEY §8a ⊕1-⊕3) ---- */
 int nb_set_state(nb_ctx* ctx, const void* x, const void* y, const void* z,

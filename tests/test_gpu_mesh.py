@@ -177,3 +177,34 @@ def test_short_range_random_configurations(seed):
     got = _accel(pos, m, dtype, L, "p3m", ngrid, eps, part="short")
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() < (1e-10 if dtype == np.float64 else 3e-5) * max(_scale(ref), 1e-300)
+
+
+@pytest.mark.parametrize("solver", ["p3m", "ewald"])
+def test_kdk_run_equals_single_steps(solver):
+    """nb_kdk_run enqueues all steps back to back (one host synchronisation); same state as step-by-step calls, bit for bit."""
+    L, n = 30.0, 5000
+    pos, m = _cloud(n, L, 8)
+    vel = np.random.default_rng(9).normal(size=(n, 3))
+    s = nb.State(pos.astype(np.float32), vel.astype(np.float32), m.astype(np.float32))
+    k1 = np.linspace(0.01, 0.02, 6); d = np.linspace(0.03, 0.02, 6); k2 = np.linspace(0.015, 0.005, 6)
+    out = []
+    for batched in (True, False):
+        with nb.Engine(n, np.float32) as e:
+            if solver == "p3m":
+                e.set_mesh("p3m", L, 32)
+            else:
+                e.set_periodic(L, 13.2, 15)
+            e.set_state(s)
+            if batched:
+                e.kdk_run(k1, d, k2, 0.1)
+            else:
+                for a, b, c in zip(k1, d, k2):
+                    e.kdk_step(a, b, c, 0.1)
+            out.append(e.get_state())
+    np.testing.assert_array_equal(out[0].pos, out[1].pos)
+    np.testing.assert_array_equal(out[0].vel, out[1].vel)
+    with nb.Engine(n, np.float32) as e:
+        e.set_state(s)
+        with pytest.raises(ValueError):
+            e.kdk_run([0.1, 0.2], [0.1], [0.1, 0.2], 0.1)
+        e.kdk_run([], [], [], 0.1)                                          # zero steps: nothing happens
