@@ -49,6 +49,14 @@ if __name__ == "__main__":
         rows.append(pb * (A_REF / a_s))
     rows = np.array(rows)
     out = np.column_stack([EDGES[:-1], EDGES[1:], cnt, kb, rows.mean(0), rows.std(0, ddof=1), np.full(len(kb), len(rows))])
-    np.savetxt(os.path.join(os.path.dirname(os.path.abspath(__file__)), "p3m_farm_ensemble_pk.txt"), out,
+    here = os.path.dirname(os.path.abspath(__file__))
+    np.savetxt(os.path.join(here, "p3m_farm_ensemble_pk.txt"), out,
                header="k_lo k_hi modes mean_k mean_P[Mpc^3] std_P n_snapshots   (P scaled to A_s = 2.105e-9; see make_p3m_ensemble.py)")
     print(out)
+    # the 100 test jobs alone, UNSCALED (the non-linear spectrum is not proportional to A_s), with their A_s values in the same order
+    test = [(float(re.search(r"A_s([0-9.e+-]+)", f).group(1)), f) for f in files if "Test_Data_concept" in f]
+    rows = np.array([binned(snapshot.read_positions(f))[1] for _, f in test])
+    np.savetxt(os.path.join(here, "p3m_farm_test100_pk.txt"),
+               np.column_stack([EDGES[:-1], EDGES[1:], cnt, kb, rows.mean(0), rows.std(0, ddof=1), np.full(len(kb), len(rows))]),
+               header="k_lo k_hi modes mean_k mean_P[Mpc^3] std_P n_snapshots   (the 100 snapshots of Test_Data_concept, unscaled; A_s per job in p3m_farm_test100_As.txt)")
+    np.savetxt(os.path.join(here, "p3m_farm_test100_As.txt"), np.array([a for a, _ in test]), header="A_s of the 100 Test_Data_concept jobs, sorted() path order")
