@@ -13,6 +13,7 @@ nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 n_side = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dtype = np.float32 if (len(sys.argv) > 4 and sys.argv[4] == "f32") else np.float64
+lpt = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 L, a_begin = 500.0, 0.02
 ref = np.loadtxt(os.path.join(ROOT, "tests", "golden", "concept", "PP_powerspec_a=1.00"))
 k_ref, modes, p_ref, p_lin = ref[:, 0], ref[:, 1].astype(int), ref[:, 2], ref[:, 4]
@@ -22,13 +23,13 @@ k_ext = np.geomspace(k_ref[-1] * 1.05, 1.0, 12)
 tab = np.column_stack([np.concatenate([k_ref, k_ext]), np.concatenate([p_lin, p_lin[-1] * (k_ext / k_ref[-1]) ** slope])])
 c = cosmo.Cosmology.from_h_omegas(0.6736, 0.02237, 0.12)
 t0 = time.perf_counter()
-pos, vel = cosmo.zeldovich_ics(tab, n_side, L, c, a_begin, seed, seed + 1000)
+pos, vel = cosmo.zeldovich_ics(tab, n_side, L, c, a_begin, seed, seed + 1000, lpt=lpt)
 mass = c.particle_mass(L, n_side ** 3)
 pos, vel = cosmo.run_pp(pos, vel, mass, L, c, a_begin, 1.0, nsteps, dtype=dtype)
 t_run = time.perf_counter() - t0
 kmag, pk = cosmo.power_modes(pos, L, n_side, interlace=True)     # CONCEPT's estimator settings: CIC, deconvolved, interlaced
 k_b, p_b = cosmo.rebin_like_concept(kmag, pk, modes if n_side == 64 else modes[: max(2, len(modes) // 2)])
-print(f"# {n_side}^3 particles, {nsteps} steps in ln a, {np.dtype(dtype).name} forces, wall {t_run:.1f} s (CONCEPT: 257257 s)")
+print(f"# {lpt}LPT ICs; {n_side}^3 particles, {nsteps} steps in ln a, {np.dtype(dtype).name} forces, wall {t_run:.1f} s (CONCEPT: 257257 s)")
 print("#  k_ref      k_here     modes   P_ref        P_here       ratio   P_ref/P_lin  P_here/P_lin")
 for i in range(len(k_b)):
     print(f"{k_ref[i]:.4e} {k_b[i]:.4e} {modes[i]:6d}  {p_ref[i]:.4e}  {p_b[i]:.4e}  {p_b[i]/p_ref[i]:6.3f}   {p_ref[i]/p_lin[i]:6.3f}      {p_b[i]/p_lin[i]:6.3f}")
