@@ -108,7 +108,8 @@ int nb_accel(nb_ctx* ctx, double eps, double G, void* ax, void* ay, void* az);
 int nb_get_acc(nb_ctx* ctx, void* ax, void* ay, void* az);
 /* nsteps KDK steps of size dt, entirely on the device (no host round trip inside the loop) */
 int nb_step(nb_ctx* ctx, double dt, int64_t nsteps, double eps, double G);
-/* kinetic and softened potential energy, accumulated in fp64 */
+/* kinetic and softened potential energy, accumulated in fp64. The potential is the ISOLATED pair sum -G/2 sum_{i != j} m_i m_j /
+ * sqrt(r^2+eps^2) whatever solver is selected: it is not the (background-subtracted) periodic potential of the Ewald / PM / P3M modes */
 int nb_energy(nb_ctx* ctx, double eps, double G, double* kinetic, double* potential);
 /* nsteps KDK steps like nb_step, plus the energies after every step: kinetic[k], potential[k] (host arrays of
  * nsteps doubles, either may be NULL) at the synchronised end of step k. The potential is accumulated inside
