@@ -54,7 +54,7 @@ def _run_cosmological(args, p, s) -> int:
     """CONCEPT-like run: Zel'dovich / 2LPT ICs at a_begin from the linear P(k) table (at a = 1) — or a snapshot to resume from —
     comoving KDK with periodic 'pp' / 'pm' / 'p3m' forces up to the last requested scale factor, snapshot and power spectrum at
     their requested output times."""
-    from . import cosmo, field, snapshot
+    from . import cosmo, snapshot
     L = s["boxsize"]
     if not p.get("H0"):
         print("concept: --cosmological needs H0/Ωb/Ωcdm in the parameter file", file=sys.stderr)

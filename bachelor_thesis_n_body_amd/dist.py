@@ -17,7 +17,7 @@ imports the oracle).
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional, Tuple
+from typing import List, Tuple
 
 import numpy as np
 
