@@ -208,3 +208,31 @@ def test_kdk_run_equals_single_steps(solver):
         with pytest.raises(ValueError):
             e.kdk_run([0.1, 0.2], [0.1], [0.1, 0.2], 0.1)
         e.kdk_run([], [], [], 0.1)                                          # zero steps: nothing happens
+
+
+def test_contexts_release_all_device_memory():
+    """A farm runs many jobs in one process: creating, using and destroying contexts of every periodic solver must not leak
+    device memory (mesh grids, FFT plans, cell lists, tables, structure factors)."""
+    import torch
+    L, n = 40.0, 20000
+    pos, m = _cloud(n, L, 12)
+    s = nb.State(pos.astype(np.float32), np.zeros((n, 3), np.float32), m.astype(np.float32))
+
+    def cycle():
+        for setup in (lambda e: e.set_mesh("pm", L, 32), lambda e: e.set_mesh("p3m", L, 32), lambda e: e.set_periodic(L, 16.5, 19),
+                      lambda e: e.set_periodic(L), lambda e: e.set_solver("tree", 0.5), None):
+            with nb.Engine(n, np.float32) as e:
+                if setup is not None:
+                    setup(e)
+                e.set_state(s)
+                e.accel(0.1, fetch=False)
+                if setup is None:
+                    e.step_with_energy(0.01, 2, 0.1)            # direct solver: the phi / energy-log buffers too
+    cycle()                                   # first use: library-level caches (hipFFT kernels, rocPRIM) are allocated once
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(5):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, (free0, free1)          # nothing accumulates (allow allocator granularity)
