@@ -46,6 +46,7 @@ struct BHBuf {
   float* out = nullptr;                      // [3][n] accelerations in sorted order
   int4* rec = nullptr;                       // all nodes: (l2 bits, first, count, left child) for the list walk
   int* gstack = nullptr;                     // wave-private stacks of the persistent list-walk waves
+  int stack_blocks = 0;                      // blocks gstack was sized for: the list walk never launches more
   int* flags = nullptr;                      // [0] = stack overflow seen
   void* tmp = nullptr; size_t tmp_bytes = 0; // rocPRIM scratch
   int64_t cap = 0;
@@ -207,7 +208,7 @@ template <bool GUARD>
 __global__ void __launch_bounds__(256)
 walk_kernel(const float4* __restrict__ sp, int n, const int2* __restrict__ child, const int2* __restrict__ range,
             const float4* __restrict__ com, const float* __restrict__ l2, float theta2, float eps2,
-            float* __restrict__ out) {
+            float* __restrict__ out, int* __restrict__ flags) {
   __shared__ int stack_all[4][STACK];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   volatile int* stack = stack_all[wave];
@@ -252,7 +253,7 @@ walk_kernel(const float4* __restrict__ sp, int n, const int2* __restrict__ child
       if (sp_top + 2 <= STACK) {
         if (lane == 0) { stack[sp_top] = ch.y; stack[sp_top + 1] = ch.x; }   // left child is popped first
         sp_top += 2;
-      }
+      } else if (lane == 0) flags[0] = 1;                                    // overflow: results invalid, reported by the host
     }
   }
   if (live) { out[i] = ax; out[(size_t)n + i] = ay; out[2 * (size_t)n + i] = az; }
@@ -463,6 +464,7 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
     {
       const int groups = (int)((N + 63) / 64), blocks = (groups + 3) / 4 < 2048 ? (groups + 3) / 4 : 2048;
       NB_HIP(c, hipMalloc((void**)&b.gstack, (size_t)blocks * 4 * LSTACK * sizeof(int)));
+      b.stack_blocks = blocks;
     }
     NB_HIP(c, hipMalloc((void**)&b.flags, 4 * sizeof(int)));
     NB_HIP(c, hipMemsetAsync(b.flags, 0, 4 * sizeof(int), st));
@@ -494,11 +496,13 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
   const int blocks = (groups + 3) / 4;
   static const int walk_mode = getenv("NB_BH_WALK") ? atoi(getenv("NB_BH_WALK")) : 1;
   if (walk_mode == 0) {
-    if (eps2 > 0.f) walk_kernel<false><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out);
-    else walk_kernel<true><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out);
+    if (eps2 > 0.f) walk_kernel<false><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out, b.flags);
+    else walk_kernel<true><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out, b.flags);
   } else {
     static const int maxb = getenv("NB_BH_BLOCKS") ? atoi(getenv("NB_BH_BLOCKS")) : 1792;   // 7 blocks per CU (VGPR-limited residency); <= 2048 (stack allocation)
-    const int pblocks = blocks < maxb ? blocks : maxb;      // persistent waves; groups are handed out dynamically
+    int pblocks = blocks < maxb ? blocks : maxb;            // persistent waves; groups are handed out dynamically
+    if (pblocks > b.stack_blocks) pblocks = b.stack_blocks; // never more waves than wave-private stacks were allocated
+    if (pblocks < 1) pblocks = 1;
     static const int nleaf = getenv("NB_BH_NLEAF") ? atoi(getenv("NB_BH_NLEAF")) : NLEAF;
     NB_HIP(c, hipMemsetAsync(b.flags + 1, 0, sizeof(int), st));                 // dynamic group counter
     if (eps2 > 0.f) walk_list_kernel<false><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.out, b.gstack, groups, b.flags, nleaf);

@@ -175,6 +175,8 @@ int nb_set_state(nb_ctx* c, const void* x, const void* y, const void* z, const v
   NB_HIP(c, hipStreamSynchronize(c->stream));
   c->acc_valid = false;
   c->has_state = true;
+  // a captured step graph bakes in the UNIFORM / general-mass kernel variant chosen for the previous masses
+  if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
   // equal masses (the standard N-body set-up) unlock the cheaper inner loop; decided on the host copy, O(N)
   bool uni = true;
   if (c->dtype == NB_F32) { const float* mm = (const float*)m; for (int64_t i = 1; i < c->n && uni; ++i) uni = mm[i] == mm[0]; }

@@ -80,7 +80,9 @@ pot_energy_partial_kernel(const double* __restrict__ phi, const T* __restrict__ 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const T mi = m[i];
     double self = 0.0;
-    if (eps2 > 0.0) {
+    // same predicate as the force launchers' GUARD choice: fp32 drops coincident pairs for eps^2 < 1e-20f (accel_f32.hip),
+    // fp64 only for eps = 0 (accel_f64.hip) — the self term is subtracted exactly when it was added
+    if (sizeof(T) == 4 ? (float)eps2 >= 1e-20f : eps2 > 0.0) {
       if (sizeof(T) == 4) {
         const float ri = __builtin_amdgcn_rsqf((float)eps2);
         self = uniform ? (double)mi * (double)ri : (double)((float)mi * ri);

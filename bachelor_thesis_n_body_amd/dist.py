@@ -45,7 +45,7 @@ class HipKernels:
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
         _lib.check(None, self._lib.nb_create(C.byref(self._ctx), 1, _lib.NB_F32, device_index), "nb_create")
-        self._stream = None
+        self._stream = self._stream_obj = None
 
     def close(self):
         if self._ctx:
@@ -59,10 +59,13 @@ class HipKernels:
             pass
 
     def _bind(self):
-        s = self._torch.cuda.current_stream().cuda_stream
+        cur = self._torch.cuda.current_stream()
+        s = cur.cuda_stream
         if s != self._stream:
             _lib.check(self._ctx, self._lib.nb_set_stream(self._ctx, C.c_void_p(s)), "nb_set_stream")
-            self._stream = s
+            # hold the Stream OBJECT, not only its handle: the context keeps using (and synchronising) the handle until the
+            # next nb_set_stream / nb_destroy, so it must not be destroyed under it (include/nbody_amd.h: nb_set_stream)
+            self._stream, self._stream_obj = s, cur
 
     @staticmethod
     def _code(t) -> int:
@@ -137,6 +140,66 @@ class HipKernels:
         _lib.check(self._ctx, self._lib.nb_drift_dev(self._ctx, self._code(vel), x, y, z, vx, vy, vz, n, dt), "nb_drift_dev")
 
 
+class HopProbe:
+    """Per-hop timing of the ring: how long each exchange took (`comm_ms`, from the moment it was posted until its data
+    had landed) next to the kernel it was posted beside (`kernel_ms`), and how long the compute stream then still had
+    to wait for it (`exposed_ms` — 0 when the hop is hidden behind the math). Device runs use HIP events: the post and
+    the kernel are bracketed on the compute stream; the arrival is observed on a side stream that waits for the
+    communicator's work only, so it does not include the kernel. Host-blocking transports (gloo) and CPU rehearsals
+    fall back to the host clock around `wait()`."""
+
+    def __init__(self, torch, device):
+        import time
+        self._t, self._clock = torch, time.perf_counter
+        self.cuda = device.type == "cuda"
+        self.side = torch.cuda.Stream(device) if self.cuda else None
+        self.enabled = False
+        self.hops = []      # per hop: (post, comm_done, kernel_begin, kernel_end, after_wait)
+
+    def _mark(self, stream=None):
+        if not self.cuda:
+            return self._clock()
+        e = self._t.cuda.Event(enable_timing=True)
+        e.record(stream) if stream is not None else e.record()
+        return e
+
+    def exchange(self, reqs, launch, host_blocking):
+        """Run `launch()` (the kernel on the chunk in hand) beside the posted requests `reqs` and time both."""
+        post = self._hold
+        k0 = self._mark()
+        launch()
+        k1 = self._mark()
+        if self.cuda and not host_blocking:
+            with self._t.cuda.stream(self.side):     # the side stream waits for the communicator only
+                for q in reqs:
+                    q.wait()
+                done = self._mark(self.side)
+            for q in reqs:
+                q.wait()                             # ... the compute stream as usual
+            self.hops.append((post, done, k0, k1, self._mark()))
+        else:
+            for q in reqs:
+                q.wait()
+            t = self._clock()
+            self.hops.append((self._host_post, t, k0, k1, self._mark()))
+
+    def posting(self):
+        self._hold = self._mark()
+        self._host_post = self._clock()
+
+    def summary(self):
+        """Means over the recorded hops (call after a device synchronise)."""
+        if not self.hops:
+            return None
+        ms = lambda a, b: a.elapsed_time(b) if self.cuda and not isinstance(a, float) else (b - a) * 1e3
+        comm = [ms(p, d) for p, d, _, _, _ in self.hops]
+        kern = [ms(k0, k1) for _, _, k0, k1, _ in self.hops] if self.cuda else [float("nan")] * len(self.hops)
+        expo = [max(0.0, ms(k1, a)) for _, _, _, k1, a in self.hops] if self.cuda else [float("nan")] * len(self.hops)
+        mean = lambda v: sum(v) / len(v)
+        return {"hops_timed": len(self.hops), "comm_ms": mean(comm), "kernel_ms": mean(kern), "exposed_ms": mean(expo),
+                "comm_ms_max": max(comm)}
+
+
 class ShardedEngine:
     """Sink-decomposed engine of one rank. All ranks must make the same sequence of calls."""
 
@@ -177,6 +240,7 @@ class ShardedEngine:
         self._acc_key = None
         self.uniform_mass = False
         self.kernel_timer = None   # optional object with begin()/end(interactions): brackets every accel launch
+        self.hop_probe = None      # optional HopProbe: per-hop exchange time next to the kernel it overlaps
 
     # -- state ----------------------------------------------------------------------------------
     def set_state(self, state: State) -> None:
@@ -245,9 +309,16 @@ class ShardedEngine:
             reqs = None
             if h < P - 1:
                 fence()
+                if self.hop_probe is not None and self.hop_probe.enabled:
+                    self.hop_probe.posting()
                 recv_buf = self.ring[h & 1]
                 ops = [dist.P2POp(dist.isend, cur, nxt_rank, self.group), dist.P2POp(dist.irecv, recv_buf, prv_rank, self.group)]
                 reqs = dist.batch_isend_irecv(ops)   # posted before the kernel so it runs beside it
+            probe = self.hop_probe if (reqs is not None and self.hop_probe is not None and self.hop_probe.enabled) else None
+            if probe is not None:
+                probe.exchange(reqs, lambda: fn(cur, (r - h) % P, h == 0), host_blocking=unordered or self.device.type != "cuda")
+                cur = recv_buf
+                continue
             fn(cur, (r - h) % P, h == 0)
             if reqs is not None:
                 for q in reqs:

@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: particle-pair interactions per second of the direct-summation KDK step.
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1: plain python; N > 1: under torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 the command launches its own N ranks (one CHILD process per GPU with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set,
+started before this process has touched torch or the GPU; a failing rank makes the command fail) unless it already runs under a
+launcher (WORLD_SIZE set — the driver's `python -m torch.distributed.run ... bench.py --gpus N` form). Extra switches:
+`--general-mass` times the 12-op per-source-mass kernel instead of the equal-mass variant, `--dtype f64 --n 524288` the fp64
+kernel, `--backend gloo --same-device` rehearses the N-rank bench on ONE GPU (tests/test_gpu_bench_contract.py).
 
 Workload (BASELINE.json metric): Plummer sphere, N = 2^20 particles, fp32, Hénon units, equal
 masses, eps = 0.01, dt = 1/256, seed 0 — synthetic, generated on the host and resident in HBM before the timed
@@ -113,6 +119,38 @@ def cpu_baseline(state, eps, budget_s=12.0):
             "sample": f"C oracle fp64 OpenMP: first {m_snk} sinks x all {n} sources of the same Plummer workload, {t:.1f} s"}
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (never an exec; nothing in THIS
+    process has imported torch or touched the GPU) with the environment torch.distributed.run would give them (RANK,
+    LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT), let rank 0's JSON line through on stdout and return
+    non-zero if any rank failed (the surviving ranks are then terminated by PID, not left waiting in a collective)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    rc, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in live:                                  # a dead rank leaves the others stuck in a collective
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,34 +159,53 @@ def main():
     ap.add_argument("--n", type=int, default=1 << 20)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--mode", choices=["ring", "allgather"], default="ring")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (default); gloo for rehearsals")
+    ap.add_argument("--same-device", action="store_true", help="all ranks share cuda:0 (one-GPU rehearsal; needs --backend gloo)")
+    ap.add_argument("--general-mass", action="store_true", help="perturb one mass by 1 ulp: times the per-source-mass kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.same_device and args.backend == "nccl" and args.gpus > 1:
+        raise SystemExit("--same-device needs --backend gloo (RCCL refuses two ranks on one device)")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
     import bachelor_thesis_n_body_amd as nb
+    from bachelor_thesis_n_body_amd.dist import HopProbe
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} disagrees with WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: no device cuda:{local_rank} ({torch.cuda.device_count()} visible); use --same-device --backend gloo to rehearse on one GPU")
     torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
     eps, dt, G = 0.01, 1.0 / 256.0, 1.0
     state = nb.plummer_sphere(args.n, seed=0, dtype=np_dtype)
-    eng = nb.ShardedEngine(args.n, np_dtype, device=torch.device("cuda", local_rank), mode=args.mode)
+    if args.general_mass:       # one mass 1 ulp up: same physics to ~1e-7/N, but no longer the equal-mass special case
+        state.mass[-1] = np.nextafter(state.mass[-1], np_dtype(1.0))
+    eng = nb.ShardedEngine(args.n, np_dtype, device=device, mode=args.mode)
     eng.set_state(state)
     timer = KernelTimer(torch)
     eng.kernel_timer = timer
+    probe = HopProbe(torch, device) if (world > 1 and args.mode == "ring") else None
+    eng.hop_probe = probe
 
     def sync():
         torch.cuda.synchronize()
@@ -161,14 +218,18 @@ def main():
         eng.step(dt, 1, eps, G)
     sync()
     timer.enabled = True
+    if probe is not None:
+        probe.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.step(dt, 1, eps, G)
     sync()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    if probe is not None:
+        probe.enabled = False
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -193,9 +254,17 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"plummer_sphere N={args.n} {args.dtype} eps=0.01 dt=1/256, KDK step = 1 all-pairs force evaluation",
-                       "n": args.n, "parallelism": f"sink-decomposition x{world}, {args.mode} exchange of source chunks"},
+                       "n": args.n, "parallelism": f"sink-decomposition x{world}, {args.mode} exchange of source chunks",
+                       "masses": "general (one mass perturbed by 1 ulp)" if args.general_mass else "equal"},
+            "world_size": world,
+            "backend": (args.backend if args.backend == "gloo" else "nccl (RCCL)") if world > 1 else None,
+            "same_device": bool(args.same_device) if world > 1 else None,
+            # rank 0's ring hops inside the timed region: exchange time vs the kernel it was posted beside, and what of it the
+            # compute stream still had to wait for (0 = hidden)
+            "ring": probe.summary() if probe is not None else None,
             "roofline": {"bound": "vector_" + ("fp32" if args.dtype == "f32" else "fp64"),
                          "kernel": "accel_%s_kernel" % args.dtype,
+                         "variant": "uniform_mass" if eng.uniform_mass else "general",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "flop_per_interaction": FLOP_PER_INTERACTION,
                          "interactions_per_launch": k_inter, "avg_launch_ms": k_ms, "launches_timed": k_count,

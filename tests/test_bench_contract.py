@@ -32,3 +32,31 @@ def test_measured_traffic_reads_the_committed_profile():
     import bench
     t = bench.measured_traffic()
     assert t is None or 1e6 < t < 1e11
+
+
+def test_bench_self_launches_its_ranks_and_propagates_their_failure(has_gpu):
+    """`python bench.py --gpus 2` is ONE command: the parent starts the launcher + ranks as children; without a GPU the ranks refuse
+    (no CPU fallback) and the parent's exit code says so."""
+    if has_gpu:
+        pytest.skip("GPU present")
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--n", "1024"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "no CPU fallback" in (out.stderr + out.stdout)
+    assert not [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_hop_probe_on_the_host_clock():
+    import torch
+    from bachelor_thesis_n_body_amd.dist import HopProbe
+
+    class Req:
+        def wait(self):
+            pass
+    p = HopProbe(torch, torch.device("cpu"))
+    p.enabled = True
+    ran = []
+    for _ in range(3):
+        p.posting()
+        p.exchange([Req(), Req()], lambda: ran.append(1), host_blocking=True)
+    s = p.summary()
+    assert len(ran) == 3 and s["hops_timed"] == 3 and s["comm_ms"] >= 0 and s["comm_ms_max"] >= s["comm_ms"]

@@ -28,3 +28,37 @@ def test_bench_prints_one_contract_json_line():
     assert r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.2 < r["frac"] < 1.0
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["value"] < j["value"]
+    assert r["variant"] == "uniform_mass" and j["world_size"] == 1 and j["ring"] is None
+
+
+def test_bench_general_mass_variant_is_labelled():
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--n", "32768", "--general-mass", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert j["roofline"]["variant"] == "general" and "general" in j["config"]["masses"]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_bench_two_ranks_self_launched_on_one_gpu(dtype):
+    """`python bench.py --gpus 2` as ONE command: the parent spawns the launcher and the two ranks, which share the test box's one GPU
+    (gloo transport, --same-device) — the bench's barrier, MAX all-reduce, rank-0 print and per-hop ring timing end to end."""
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "65536", "--dtype", dtype,
+                          "--backend", "gloo", "--same-device"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stderr[-3000:], out.stdout[-1000:])
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["world_size"] == 2 and j["backend"] == "gloo" and j["same_device"] is True and j["scaling"] == "strong"
+    assert j["dtype"] == dtype and j["value"] == pytest.approx(65536 ** 2 * 3 / (j["ms_per_step"] * 3e-3), rel=1e-6)
+    ring = j["ring"]
+    assert ring["hops_timed"] == 3 and ring["comm_ms"] > 0 and ring["kernel_ms"] > 0 and ring["exposed_ms"] >= 0
+    r = j["roofline"]
+    assert r["launches_timed"] == 6 and r["interactions_per_launch"] == 32768.0 ** 2 and 0.05 < r["frac"] < 1.0
+    assert "cpu_baseline" not in j          # rank 0 at N = 1 only
+
+
+def test_bench_propagates_a_failing_rank():
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--n", "4096"],
+                         capture_output=True, text=True, timeout=600)      # RCCL on a one-GPU box: rank 1 has no device
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.strip().startswith("{")]

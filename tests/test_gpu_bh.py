@@ -119,3 +119,22 @@ def test_ballot_walk_variant_matches_its_oracle(bho):
     env = dict(os.environ, NB_BH_WALK="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_config4_tree_n16M_full_size(coracle):
+    """configs[4]: Barnes-Hut, theta = 0.5, N = 16 777 216 on one GPU — finite, no stack overflow (nb_accel reports it as an error),
+    256 sampled sinks against the oracle's DIRECT sum over all 16 M sources (the method check, not the tree restatement)."""
+    n = 1 << 24
+    s = nb.plummer_sphere(n, 0, np.float32)
+    with nb.Engine(n, np.float32) as e:
+        e.set_state(s)
+        e.set_solver("tree", 0.5)
+        a = e.accel(0.01)                   # raises RuntimeError if the device flagged a stack overflow
+    assert np.all(np.isfinite(a))
+    idx = np.random.default_rng(0).choice(n, 256, replace=False)
+    ref = coracle.accel(s.pos, s.mass, 0.01, sinks=s.pos[idx])
+    err = rel_err(a[idx], ref)
+    assert np.median(err) < 3e-3 and err.max() < 0.05, (np.median(err), err.max())
+    m64 = s.mass.astype(np.float64)
+    net = np.abs((m64[:, None] * a).sum(0)).max()
+    assert net < 2e-3 * (m64[:, None] * np.abs(a)).sum(0).max()      # monopole BH conserves momentum only to the force error

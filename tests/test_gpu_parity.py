@@ -322,3 +322,66 @@ def test_energy_conservation_large_n(dtype, tol):
     e0, e1 = k0 + u0, k1 + u1
     assert abs(2 * k0 / abs(u0) - 1) < 0.02 and abs(e0 + 0.25) < 0.01       # virial, Hénon units
     assert abs(e1 - e0) / abs(e0) < tol, f"dE/E = {(e1 - e0) / abs(e0):.3e}"
+
+
+# ------------------------------------------------------------------ regression: stale step graph after nb_set_state
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_set_state_with_new_masses_invalidates_the_captured_step_graph(dtype):
+    """A graph captured for equal masses bakes in the UNIFORM kernel variant (masses ignored, m[0] applied at the end); a second
+    nb_set_state with unequal masses on the SAME context must not replay it."""
+    n = 3000
+    s1 = nb.plummer_sphere(n, 41, dtype)
+    s2 = nb.plummer_sphere(n, 42, dtype)
+    s2.mass = (s2.mass * np.random.default_rng(3).uniform(0.25, 4.0, n)).astype(dtype)
+    with nb.Engine(n, dtype) as e:
+        e.set_state(s1)
+        e.step(1 / 256, 8, 0.01)            # eager step 0 + 7 replays of the equal-mass graph
+        e.set_state(s2)
+        e.step(1 / 256, 8, 0.01)            # same dt / eps / G: the stale graph would be reused
+        got = e.get_state()
+    with nb.Engine(n, dtype) as e:
+        e.set_state(s2)
+        e.step(1 / 256, 8, 0.01)
+        ref = e.get_state()
+    np.testing.assert_array_equal(got.pos, ref.pos)
+    np.testing.assert_array_equal(got.vel, ref.vel)
+    o = ora.State(s2.pos.astype(np.float64), s2.vel.astype(np.float64), s2.mass.astype(np.float64))
+    ora.step(o, 1 / 256, 8, eps=0.01)
+    assert np.abs(got.pos.astype(np.float64) - o.pos).max() < (2e-5 if dtype == np.float32 else 1e-11)
+
+
+@pytest.mark.parametrize("eps", [1e-12, 3e-11])
+def test_fused_potential_self_term_follows_the_kernels_guard_fp32(eps):
+    """fp32 force kernels drop coincident pairs for eps^2 < 1e-20 (GUARD variant): the O(N) self-term removal must use the same
+    predicate, or it subtracts m_i * rsq(eps^2) ~ 1e10 m_i that was never added."""
+    s = nb.plummer_sphere(2048, 43, np.float32)
+    with nb.Engine(s.n, np.float32) as e:
+        e.set_state(s)
+        k_f, u_f = e.step_with_energy(1 / 1024, 1, eps)
+        k_s, u_s = e.energy(eps)
+    assert np.isfinite(u_f[0]) and u_f[0] == pytest.approx(u_s, rel=5e-6) and k_f[0] == pytest.approx(k_s, rel=1e-6)
+    assert -1.0 < u_f[0] < -0.3
+
+
+# ------------------------------------------------------------------ BASELINE configs[3] at full size on one GPU
+def test_config3_n4M_fp64_full_size(coracle):
+    """configs[3]: N = 2^22 = 4 194 304, fp64, direct summation. One force evaluation is 1.76e13 interactions (~9.4 s on one MI355X):
+    64 sampled sinks against the C oracle over ALL sources at 1e-10, Newton's third law, then 4 energy-monitored KDK steps
+    (fused potential) with |dE/E| at the integrator's level."""
+    n = 1 << 22
+    s = nb.plummer_sphere(n, 0, np.float64)
+    with nb.Engine(n, np.float64) as e:
+        e.set_state(s)
+        a = e.accel(0.01)
+        assert np.all(np.isfinite(a))
+        net = np.abs((s.mass[:, None] * a).sum(0)).max()
+        assert net < 1e-12 * (s.mass[:, None] * np.abs(a)).sum(0).max()
+        idx = np.random.default_rng(0).choice(n, 64, replace=False)
+        ref = coracle.accel(s.pos, s.mass, 0.01, sinks=s.pos[idx])
+        assert rel_err(a[idx], ref).max() < 1e-10
+        k0, u0 = e.energy(0.01)
+        K, U = e.step_with_energy(1 / 256, 4, 0.01)
+    e0 = k0 + u0
+    assert abs(2 * k0 / abs(u0) - 1) < 0.02 and abs(e0 + 0.25) < 0.01
+    drift = np.abs((K + U) - e0).max() / abs(e0)
+    assert drift < 1e-7, f"max |dE/E| over 4 steps = {drift:.3e}"
