@@ -6,8 +6,8 @@
 // rsqrt, so m/r^3 is built from a hardware rsqrt seed and a second-order correction in h = 1 - r2*y^2:
 //     y  = v_rsq_f64(r2)                       (~2^-26 relative)  [RSQ_MODE 0]
 //     y  = (double) v_rsq_f32((float) r2)      (~2^-23 relative)  [RSQ_MODE 1; r2 must fit fp32 range]
-//     h  = 1 - r2*y^2 ;  m/r^3 = m y^3 (1 + 3h/2 + 15h^2/8)       -> relative error ~ 3h^3 < 1e-20
-// Per interaction: 3 add, 3 fma, seed, 7 (m/r^3), 3 fma = 16 fp64 VALU + seed.
+//     h  = 1 - r2*y^2 ;  m/r^3 = m y^3 (1 + 3h/2) = (3/2) m y^3 (5/3 - r2 y^2)   -> relative error 15/8 h^2 < 2e-15
+// Per interaction: 3 add, 3 fma, seed, 4 (+1 with per-source masses) for m/r^3, 3 fma = 13 (14) fp64 VALU + seed.
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
 #include <cstdlib>
@@ -17,20 +17,23 @@ namespace {
 constexpr int BLOCK = 256;
 struct d4 { double x, y, z, w; };
 
-// m / (r2)^{3/2} from a hardware rsqrt seed y ~ r2^{-1/2}:  with h = 1 - r2*y^2,
-//   r2^{-3/2} = y^3 (1-h)^{-3/2} = y^3 (1 + 3/2 h + 15/8 h^2 + O(h^3)),   |h| <~ 2^-23  ->  error ~ 3 h^3 < 1e-20
-// 7 fp64 VALU ops after the seed (one fewer than refining y first and cubing afterwards).
+// (2/3) m / (r2)^{3/2} from a hardware rsqrt seed y ~ r2^{-1/2}:  with u = y^2 and h = 1 - r2 u,
+//   r2^{-3/2} = y^3 (1-h)^{-3/2} = y^3 (1 + 3/2 h + O(h^2)) = (3/2) y^3 (5/3 - r2 u)
+// -> u = y*y; q = fma(-r2, u, 5/3); y3 = u*y; f = y3*q : FOUR fp64 ops after the seed, the constant 3/2 goes into the epilogue with G.
+// Truncation error 15/8 h^2: |h| <~ 2^-25 for v_rsq_f64 -> < 2e-15 relative (measured against the fp64 oracle: DESIGN.md §3.2);
+// the second-order term the first version carried (6 ops) bought nothing measurable and cost 10 % of the launch.
+// Potential: (2) m r2^{-1/2} = m y (1 + h/2 + O(h^2)) = (1/2) m y (3 - r2 u), two more ops, the 1/2 in the epilogue.
+constexpr double F_SCALE = 1.5, P_SCALE = 0.5;
 template <int RSQ_MODE, bool POT, bool UNIFORM>
 __device__ inline double m_over_r3(double m, double r2, double& m_over_r) {
   double y;
-  if (RSQ_MODE == 1) y = (double)__builtin_amdgcn_rsqf((float)r2);   // r2 must fit the fp32 range
+  if (RSQ_MODE == 1) y = (double)__builtin_amdgcn_rsqf((float)r2);   // r2 must fit the fp32 range; |h| ~ 2^-22: error ~1e-13
   else y = __builtin_amdgcn_rsq(r2);                                   // v_rsq_f64
-  const double y2 = y * y;
-  const double h = fma(-r2, y2, 1.0);
-  const double q = fma(fma(1.875, h, 1.5), h, 1.0);
+  const double u = y * y;
+  const double q = fma(-r2, u, 5.0 / 3.0);
   const double my = UNIFORM ? y : m * y;          // uniform mass: the common factor is applied once, in the epilogue
-  if (POT) m_over_r = my * fma(fma(0.375, h, 0.5), h, 1.0);     // m r2^{-1/2} = m y (1 + h/2 + 3h^2/8)
-  return (my * y2) * q;
+  if (POT) m_over_r = my * fma(-r2, u, 3.0);
+  return (my * u) * q;
 }
 
 template <int KS, int TILE, bool GUARD, int RSQ_MODE, bool POT, bool UNIFORM>
@@ -117,11 +120,11 @@ accel_f64_kernel(const double* __restrict__ xi, const double* __restrict__ yi, c
     for (int k = 0; k < KS; ++k) {
       const int i = i0 + k * BLOCK;
       if (i < n_snk) {
-        const double g = UNIFORM ? G * ms[0] : G;
+        const double g = F_SCALE * (UNIFORM ? G * ms[0] : G);
         double ox = g * fx[k], oy = g * fy[k], oz = g * fz[k];
         if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
         ax[i] = ox; ay[i] = oy; az[i] = oz;
-        if (POT) { const double ph = UNIFORM ? ms[0] * fp[k] : fp[k]; phi[i] = accumulate ? phi[i] + ph : ph; }
+        if (POT) { const double ph = P_SCALE * (UNIFORM ? ms[0] * fp[k] : fp[k]); phi[i] = accumulate ? phi[i] + ph : ph; }
       }
     }
   } else {
@@ -151,8 +154,8 @@ accel_reduce_f64_kernel(const double* __restrict__ part, int nsplit, int n_snk, 
     sx += p[i]; sy += p[(size_t)n_snk + i]; sz += p[2 * (size_t)n_snk + i];
     if (phi) sp += p[3 * (size_t)n_snk + i];
   }
-  if (phi) { const double ph = m0 ? m0[0] * sp : sp; phi[i] = accumulate ? phi[i] + ph : ph; }
-  const double g = m0 ? G * m0[0] : G;             // uniform-mass mode: common mass applied here
+  if (phi) { const double ph = P_SCALE * (m0 ? m0[0] * sp : sp); phi[i] = accumulate ? phi[i] + ph : ph; }
+  const double g = F_SCALE * (m0 ? G * m0[0] : G);   // uniform-mass mode: common mass applied here; 3/2 of the h-series (m_over_r3)
   double ox = g * sx, oy = g * sy, oz = g * sz;
   if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
   ax[i] = ox; ay[i] = oy; az[i] = oz;
