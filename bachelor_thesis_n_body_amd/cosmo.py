@@ -51,6 +51,18 @@ class Cosmology:
         a = np.linspace(a0, a1, n)
         return float(np.trapezoid(1.0 / (a ** 3 * self.H(a)), a))
 
+    def cosmic_time(self, a: float) -> float:
+        """t(a) = int_0^a da' / (a' H(a')) [Gyr] — CONCEPT's clock: its logs print `Cosmic time` and `Step size` per base step
+        (…/params_id0200_*.log:49-52) and its power-spectrum tables the time of the dump (`t = 13.814035 Gyr, a = 1`,
+        PPPMP3M/PP/powerspec/powerspec_a=1.00:1), both reproduced by this integral (tests/test_step_schedule.py)."""
+        from scipy.integrate import quad
+        return float(quad(lambda x: 1.0 / (x * float(self.H(x))), 0.0, float(a), epsabs=0, epsrel=1e-11)[0])
+
+    def scale_factor(self, t: float) -> float:
+        """a(t), inverse of cosmic_time (bracketing root find; flat LCDM with radiation)."""
+        from scipy.optimize import brentq
+        return float(brentq(lambda a: self.cosmic_time(a) - float(t), 1e-8, 4.0, xtol=1e-15, rtol=1e-13))
+
     def growth(self, a: float):
         """(D(a) with D(1) = 1, f = dlnD/dlna) of sub-horizon matter perturbations, from the linear growth ODE
             D'' + (2 + dlnH/dlna) D' - (3/2) Omega_m(a) D = 0      (' = d/dlna)
@@ -174,23 +186,62 @@ def concept_power_table(pos, boxsize: float, ngrid: int, pk_table=None, growth: 
     return tuple(out)
 
 
+def load_concept_schedule(path=None):
+    """CONCEPT's base time steps as its logs record them: the table extracted from the reference's 300 run
+    logs by tests/golden/concept/make_step_schedule.py — identical in all 300 (the base step is set by the background: constant
+    in cosmic time for 8 steps, then updated; 143 steps from a = 0.02 to 1 for the 32^3 `p3m` farm jobs of NN.param).
+    Returns (a_start[n], t_start[n] in Gyr, dt[n] in Gyr)."""
+    from pathlib import Path
+    if path is None:
+        path = Path(__file__).resolve().parent / "data" / "concept_step_schedule.txt"
+    tab = np.loadtxt(path)
+    return tab[:, 1].copy(), tab[:, 2].copy(), tab[:, 3].copy()
+
+
+def concept_time_edges(cosmo: Cosmology, a_begin: float, a_end: float, dt_steps) -> np.ndarray:
+    """Step boundaries in COSMIC TIME for a run from a_begin to a_end that takes CONCEPT's logged step sizes `dt_steps` [Gyr] in
+    order (the last step is cut at t(a_end), as CONCEPT cuts its last step at an output time; steps beyond a_end are dropped; if the
+    sizes run out before a_end the last one is repeated)."""
+    t0, t1 = cosmo.cosmic_time(a_begin), cosmo.cosmic_time(a_end)
+    edges, k = [t0], 0
+    dts = [float(v) for v in dt_steps]
+    while edges[-1] < t1 * (1.0 - 1e-12):
+        dt = dts[min(k, len(dts) - 1)]
+        nxt = edges[-1] + dt
+        edges.append(t1 if nxt >= t1 * (1.0 - 1e-9) else nxt)
+        k += 1
+    return np.array(edges)
+
+
 def run_pp(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: float, a_end: float = 1.0, nsteps: int = 400,
            eps: Optional[float] = None, alpha_L: Optional[float] = None, kmax: Optional[int] = None,
            callback: Optional[Callable[[float, "object"], None]] = None, device: int = 0, dtype=np.float64,
            gravity: str = "pp", ngrid: Optional[int] = None, interlace: bool = True, scale_cells: float = 1.25,
-           range_scales: float = 4.5):
+           range_scales: float = 4.5, schedule=None):
     """Comoving periodic run on the GPU with `nsteps` steps uniform in ln a. Returns (pos, vel) at a_end.
     gravity = 'pp' (Ewald summation; dtype float32 selects the fp32 kernels, forces good to ~1e-5. Default splitting
     alpha_L = 16.5, kmax = 19: the real-space terms have died out within a fifth of the box and are summed from cell lists;
     alpha_L = 6.2, kmax = 7 selects the all-pairs minimum-image real-space sum, `nb_set_periodic`),
     'pm' or 'p3m' (mesh of ngrid^3 cells, default cbrt(N) / 2 cbrt(N) as in CONCEPT) — the three solvers of
-    PPPMP3M/pppmp3mplotter.py:14."""
+    PPPMP3M/pppmp3mplotter.py:14.
+    schedule: None = `nsteps` steps uniform in ln a, kicks split at the geometric mean of the step's scale factors;
+    "concept" = CONCEPT's own base steps (`load_concept_schedule`: the step sizes its logs record, constant in cosmic time over
+    8 steps), or an explicit array of step sizes dt [Gyr] — then the kick halves meet at the step's mid-TIME, as in a leapfrog
+    advanced in t. `nsteps` is ignored when a schedule is given."""
     from .api import Engine
     from .state import State
     n = pos.shape[0]
     if eps is None:
         eps = 0.03 * boxsize / round(n ** (1.0 / 3.0))
-    edges = np.exp(np.linspace(np.log(a_begin), np.log(a_end), nsteps + 1))
+    if schedule is None:
+        edges = np.exp(np.linspace(np.log(a_begin), np.log(a_end), nsteps + 1))
+        mids = np.sqrt(edges[:-1] * edges[1:])
+    else:
+        dts = load_concept_schedule()[2] if isinstance(schedule, str) and schedule == "concept" else np.asarray(schedule, np.float64)
+        t_edges = concept_time_edges(cosmo, a_begin, a_end, dts)
+        edges = np.array([cosmo.scale_factor(t) for t in t_edges])
+        edges[0], edges[-1] = a_begin, a_end
+        mids = np.array([cosmo.scale_factor(0.5 * (ta + tb)) for ta, tb in zip(t_edges[:-1], t_edges[1:])])
     if gravity not in ("pp", "pm", "p3m"):
         raise ValueError("gravity must be 'pp', 'pm' or 'p3m'")
     with Engine(n, dtype, device) as e:
@@ -202,13 +253,11 @@ def run_pp(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: flo
                        interlace)
         e.set_state(State(np.asarray(pos, dtype), np.asarray(vel, dtype), np.full(n, mass, dtype)))
         if callback is None:                       # the whole run as one call: no host round trip between the steps
-            mids = np.sqrt(edges[:-1] * edges[1:])
             e.kdk_run([cosmo.kick_factor(a0, am) for a0, am in zip(edges[:-1], mids)],
                       [cosmo.drift_factor(a0, a1) for a0, a1 in zip(edges[:-1], edges[1:])],
                       [cosmo.kick_factor(am, a1) for am, a1 in zip(mids, edges[1:])], eps, _params.G_NEWTON)
         else:
-            for a0, a1 in zip(edges[:-1], edges[1:]):
-                am = np.sqrt(a0 * a1)
+            for a0, a1, am in zip(edges[:-1], edges[1:], mids):
                 e.kdk_step(cosmo.kick_factor(a0, am), cosmo.drift_factor(a0, a1), cosmo.kick_factor(am, a1), eps, _params.G_NEWTON)
                 callback(float(a1), e)
         st = e.get_state()
@@ -257,3 +306,36 @@ def rebin_like_concept(k_modes, p_modes, half_mode_counts):
         out_k.append(k[start:stop].mean()); out_p.append(p[start:stop].mean())
         start = stop
     return np.array(out_k), np.array(out_p)
+
+
+def rebin_corrected_like_concept(k_modes, p_modes, plin_modes, noise_power_modes, half_mode_counts):
+    """`P corrected` of a CONCEPT table in the table's own bins (consecutive |k|-ordered groups of 2 x `half_mode_counts` modes):
+    P_bin x sum(P_lin) / sum(P_lin |R_k|^2) — the realisation correction of `concept_power_table`, which divides out the power the
+    run's own primordial noise R put into the bin, so that two runs with different seeds compare without cosmic variance
+    (column 4 of PPPMP3M/PP/powerspec/powerspec_a=1.00:11-26)."""
+    order = np.argsort(k_modes, kind="stable")
+    k, p = np.asarray(k_modes)[order], np.asarray(p_modes)[order]
+    pl, r2 = np.asarray(plin_modes)[order], np.asarray(noise_power_modes)[order]
+    out_k, out_p, out_c, start = [], [], [], 0
+    for c in half_mode_counts:
+        stop = min(len(k), start + 2 * int(c))
+        if stop <= start:
+            break
+        sl = slice(start, stop)
+        out_k.append(k[sl].mean()); out_p.append(p[sl].mean())
+        out_c.append(p[sl].mean() * pl[sl].sum() / (pl[sl] * r2[sl]).sum())
+        start = stop
+    return np.array(out_k), np.array(out_p), np.array(out_c)
+
+
+def sigma8_of_table(k, p, h: float, radius: float = 8.0) -> float:
+    """The sigma_8 a CONCEPT power-spectrum table prints in its header (`σ₈ = 8.77e-01`, PPPMP3M/PP/powerspec/powerspec_a=1.00:9):
+    rms top-hat (R = 8 Mpc/h) overdensity of the TABULATED spectrum only, i.e. over the k range the box resolves —
+        sigma^2 = 1/(2 pi^2) int k^2 P(k) W(kR)^2 dk,   W(x) = 3 (sin x - x cos x) / x^3,
+    trapezoidal in k over the table's bins plus the piece below the first bin with P held at its first value. Reproduces all nine
+    header values of the reference's PP / PM / P3M tables to their three printed digits +- 1 (tests/test_step_schedule.py)."""
+    k, p = np.asarray(k, np.float64), np.asarray(p, np.float64)
+    x = k * (radius / h)
+    w = 3.0 * (np.sin(x) - x * np.cos(x)) / x ** 3
+    f = k ** 2 * p * w ** 2
+    return float(np.sqrt((np.trapezoid(f, k) + p[0] * k[0] ** 3 / 3.0) / (2.0 * np.pi ** 2)))
