@@ -59,3 +59,45 @@ def test_zeldovich_particles_match_oracle_and_feed_the_field_chain():
     # generated ICs -> CIC -> P(k): the loop the thesis closes in CiC/3D startbetingelser1.py:274-315
     k, pk, cnt = field.power_spectrum(got, L, N, deconvolve=True)
     assert np.all(np.isfinite(pk)) and cnt.sum() == N ** 3 - 1
+
+
+def test_generated_ensemble_matches_the_references_shipped_fields():
+    """Statistical pin of the generator against the reference's own GRF data: tests/golden/concept/grf_test_fields_ensemble.txt holds
+    the ensemble spectrum and variance of the 100 fields under Datafolder4/Test data (make_grf_ensemble.py beside it — which also
+    establishes that they were generated with |k| = 2 pi |n| / 10000 Mpc for the spectrum and fac = sqrt(2 pi / 500^3) N^3 for the
+    amplitude: `Cosmo data create (new).py`:275 vs BoxParams.txt). 100 fields generated HERE with that convention and the linear model
+    of the fixture must show the same variance and the same spectrum bin by bin."""
+    from pathlib import Path
+    fx_path = Path(__file__).resolve().parent / "golden" / "concept" / "grf_test_fields_ensemble.txt"
+    fx = np.loadtxt(fx_path)
+    hdr = [l for l in open(fx_path) if "variance of a field" in l][0].split()
+    var_ref, var_std = float(hdr[hdr.index("mean") + 1]), float(hdr[hdr.index("std") + 1])
+    N, L = 32, 500.0
+    n = np.fft.fftfreq(N, d=1.0 / N)
+    nmag = np.sqrt(n[:, None, None] ** 2 + n[None, :, None] ** 2 + n[None, None, :] ** 2)
+    P = np.exp(np.interp(np.log(np.maximum(nmag, 0.5)), np.log(fx[:, 0]), np.log(fx[:, 4])))      # the fixture's linear model in |n|
+    P[0, 0, 0] = 0.0
+    fac2 = 2 * np.pi / L ** 3 * N ** 6
+    edges = np.arange(0.5, 28.5, 1.0)
+    which = np.digitize(nmag.ravel(), edges) - 1
+    ok = (which >= 0) & (which < len(edges) - 1)
+    cnt = np.bincount(which[ok], minlength=len(edges) - 1)
+    np.testing.assert_array_equal(cnt[cnt > 0], fx[:, 1].astype(int))
+    rng = np.random.default_rng(2024)
+    spec, var = [], []
+    with grf.GRFPlan(N, L) as p:
+        p.set_spectrum(P)
+        for _ in range(100):
+            p.set_noise(rng.normal(0, 1 / np.sqrt(2), (N,) * 3), rng.normal(0, 1 / np.sqrt(2), (N,) * 3), "assign_self")
+            d = p.field(0)
+            var.append(d.var())
+            pk = np.abs(np.fft.fftn(d)) ** 2 / fac2
+            spec.append((np.bincount(which[ok], weights=pk.ravel()[ok], minlength=len(edges) - 1) / np.maximum(cnt, 1))[cnt > 0])
+    spec, var = np.mean(spec, axis=0), np.array(var)
+    # variance of a field: reference 126.67 +- 1.03 per field (0.10 on the mean of 100)
+    assert var.mean() == pytest.approx(var_ref, rel=0.01), (var.mean(), var_ref)
+    assert var.std(ddof=1) == pytest.approx(var_std, rel=0.35)
+    ratio = spec / fx[:, 2]
+    err = np.sqrt(2.0) * fx[:, 3] / fx[:, 2] / 10.0                      # scatter of the ratio of two 100-field means
+    assert np.all(np.abs(ratio - 1.0) < 4 * err + 0.01), np.column_stack([fx[:, 0], ratio, err])
+    assert abs(np.average(ratio, weights=fx[:, 1]) - 1.0) < 0.01
