@@ -14,7 +14,7 @@ the same subset, so that engine state round-trips through files the thesis scrip
 from __future__ import annotations
 
 import struct
-from typing import Any, Dict, List, Tuple
+from typing import Optional, Any, Dict, List, Tuple
 
 import numpy as np
 
@@ -271,10 +271,15 @@ class _Writer:
         self.put(o, struct.pack("<BBHII4x", 1, 0, len(msgs), 1, len(enc)) + enc)
         return o
 
-    def dataset(self, arr: np.ndarray, attrs=None) -> int:
+    def dataset(self, arr: np.ndarray, attrs=None, data_addr: Optional[int] = None) -> int:
+        """Object header of a contiguous dataset. With `data_addr` the raw data is NOT stored here: the caller places it at that
+        file offset (write_snapshot keeps all metadata in front and the arrays behind, as in the reference's files)."""
         arr = np.ascontiguousarray(arr, "<f8")
-        data = self.alloc(arr.nbytes)
-        self.put(data, arr.tobytes())
+        if data_addr is None:
+            data = self.alloc(arr.nbytes)
+            self.put(data, arr.tobytes())
+        else:
+            data = int(data_addr)
         msgs = [(0x01, self._space_msg(arr.shape)), (0x03, self._dtype_msg(arr.dtype)),
                 (0x08, struct.pack("<BBQQ", 3, 1, data, arr.nbytes))]
         for k, v in (attrs or {}).items():
@@ -325,18 +330,29 @@ def write_snapshot(filename: str, pos: np.ndarray, mom: np.ndarray, boxsize: flo
     pos, mom = np.asarray(pos, np.float64), np.asarray(mom, np.float64)
     if pos.ndim != 2 or pos.shape[1] != 3 or mom.shape != pos.shape:
         raise ValueError("pos and mom must both have shape (N, 3)")
-    w = _Writer()
-    w.alloc(96)                                   # superblock v0 + root symbol-table entry
-    h_pos, h_mom = w.dataset(pos), w.dataset(mom)
-    g_matter, _, _ = w.group({"pos": h_pos, "mom": h_mom}, {"mass": float(mass), "N": float(pos.shape[0])})
-    g_comp, _, _ = w.group({"matter": g_matter})
+    pos_le, mom_le = np.ascontiguousarray(pos, "<f8"), np.ascontiguousarray(mom, "<f8")
     root_attrs = {"boxsize": float(boxsize), "unit length": unit_length, "unit time": unit_time, "unit mass": unit_mass}
     root_attrs.update(extra_attrs or {})
-    g_root, tree, heap = w.group({"components": g_comp}, root_attrs)
-    eof = len(w.buf)
+    # File layout of the reference's snapshots (a 32^3 file is 1 583 104 B = 10 240 + 2 x 786 432): all metadata in the
+    # first META bytes, `pos` at byte META, `mom` directly behind it, nothing after. META = 10 240 unless the attributes need more.
+    meta = 10240
+    while True:
+        w = _Writer()
+        w.alloc(96)                                   # superblock v0 + root symbol-table entry
+        h_pos = w.dataset(pos_le, data_addr=meta)
+        h_mom = w.dataset(mom_le, data_addr=meta + pos_le.nbytes)
+        g_matter, _, _ = w.group({"pos": h_pos, "mom": h_mom}, {"mass": float(mass), "N": float(pos.shape[0])})
+        g_comp, _, _ = w.group({"matter": g_matter})
+        g_root, tree, heap = w.group({"components": g_comp}, root_attrs)
+        if len(w.buf) <= meta:
+            break
+        meta = (len(w.buf) + 2047) // 2048 * 2048
+    eof = meta + pos_le.nbytes + mom_le.nbytes
     sb = _SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, 4, 16, 0)
     sb += struct.pack("<QQQQ", 0, _UNDEF, eof, _UNDEF)
     sb += struct.pack("<QQII", 0, g_root, 1, 0) + struct.pack("<QQ", tree, heap)
     w.put(0, sb)
     with open(filename, "wb") as fh:
-        fh.write(bytes(w.buf))
+        fh.write(bytes(w.buf).ljust(meta, b"\0"))
+        fh.write(pos_le.tobytes())
+        fh.write(mom_le.tobytes())

@@ -103,3 +103,52 @@ def test_snapshot_reader_and_writer_roundtrip(tmp_path):
         sn.read_positions(str(bad))
     with pytest.raises(KeyError):
         sn.read_dataset(str(src), "components/nope/pos")
+
+
+def test_writer_reproduces_the_byte_layout_of_a_reference_snapshot(tmp_path):
+    """A reference snapshot pushed through write_snapshot comes out with the reference's own layout: same file size
+    (1 583 104 B for 32^3), `pos` at byte 10 240, `mom` at 10 240 + 786 432, both bit-identical to the source file's data blocks —
+    the writer is pinned by the reference's bytes, not only by this package's reader. The attributes the thesis scripts and a resumed
+    CONCEPT-style run need (boxsize, a, H0, units, mass, N) survive too."""
+    src = G / "test_id0200_snapshot_a=1.00.hdf5"
+    raw = src.read_bytes()
+    attrs, comp = sn.read_attrs(str(src)), sn.read_attrs(str(src), "components/matter")
+    out = tmp_path / "again.hdf5"
+    sn.write_snapshot(str(out), sn.read_positions(str(src)), sn.read_momenta(str(src)), attrs["boxsize"], mass=comp["mass"],
+                      extra_attrs={"a": attrs["a"], "H0": attrs["H0"]})
+    new = out.read_bytes()
+    assert len(new) == len(raw) == 1583104
+    assert new[10240:] == raw[10240:]                         # pos block + mom block, byte for byte
+    assert new[:8] == raw[:8] == b"\x89HDF\r\n\x1a\n"
+    a2, c2 = sn.read_attrs(str(out)), sn.read_attrs(str(out), "components/matter")
+    assert a2["boxsize"] == attrs["boxsize"] and a2["a"] == attrs["a"] and a2["H0"] == attrs["H0"]
+    assert c2["mass"] == comp["mass"] and c2["N"] == comp["N"]
+    np.testing.assert_array_equal(sn.read_positions(str(out)), sn.read_positions(str(src)))
+    # a different particle number keeps the layout rule: metadata first, arrays behind, nothing after
+    small = tmp_path / "small.hdf5"
+    sn.write_snapshot(str(small), np.zeros((10, 3)), np.ones((10, 3)), 1.0)
+    assert small.stat().st_size == 10240 + 2 * 240 and small.read_bytes()[10240 + 240:] == np.ones((10, 3)).tobytes()
+
+
+def test_particle_mass_and_hubble_rate_match_the_reference_snapshot_attributes():
+    """The reference's snapshots carry CONCEPT's own numbers for the unit system: root attribute H0 [1/Gyr] and components/matter `mass`
+    [1e10 M_sun] — the mean matter density of the box divided over the particles. `Cosmology` reproduces both from the parameter file's
+    H0 = 67.36 km/s/Mpc, omega_b, omega_cdm (NN.param:87-89) — G, the unit conversions and Omega_m in one number."""
+    from bachelor_thesis_n_body_amd import cosmo
+    src = G / "test_id0200_snapshot_a=1.00.hdf5"
+    c = cosmo.Cosmology.from_h_omegas(0.6736, 0.02237, 0.12)
+    a = sn.read_attrs(str(src))
+    assert c.H0 == pytest.approx(a["H0"], rel=1e-9)
+    assert c.Om == pytest.approx(a["Ωb"] + a["Ωcdm"], rel=1e-12)
+    assert c.particle_mass(500.0, 32 ** 3) == pytest.approx(sn.read_attrs(str(src), "components/matter")["mass"], rel=2e-7)
+
+
+def test_momentum_fixture_obeys_linear_continuity():
+    """p3m_farm_test100_momentum.txt (reference `mom` datasets): at the lowest k the divergence spectrum of the momentum density is
+    (a^2 H f)^2 P_delta — the reference's momenta ARE a^2 m dx/dt in Mpc / Gyr, the variable this library integrates."""
+    from bachelor_thesis_n_body_amd import cosmo
+    c = cosmo.Cosmology.from_h_omegas(0.6736, 0.02237, 0.12)
+    pdiv = np.loadtxt(G / "p3m_farm_test100_momentum.txt")[:, 4]
+    pdel = np.loadtxt(G / "p3m_farm_test100_pk.txt")[:, 4]
+    lin = (float(c.H(1.0)) * c.growth(1.0)[1]) ** 2
+    assert pdiv[0] / pdel[0] == pytest.approx(lin, rel=0.03) and pdiv[1] / pdel[1] == pytest.approx(lin, rel=0.06)
