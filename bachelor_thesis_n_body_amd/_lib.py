@@ -25,6 +25,8 @@ SIGNATURES = {
     "nb_device_count": (_int, []),
     "nb_last_error": (C.c_char_p, [_vp]),
     "nb_create": (_int, [C.POINTER(_vp), _i64, _int, _int]),
+    "nb_create_multi": (_int, [C.POINTER(_vp), _i64, _int, _int, C.POINTER(_int)]),
+    "nb_multi_layout": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), _int]),
     "nb_destroy": (_int, [_vp]),
     "nb_set_stream": (_int, [_vp, _vp]),
     "nb_synchronize": (_int, [_vp]),

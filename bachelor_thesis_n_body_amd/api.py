@@ -31,16 +31,34 @@ def _ptr(a: Optional[np.ndarray]):
 
 
 class Engine:
-    """One nb_ctx: `n` particles resident on one MI355X, state kept as SoA in HBM between calls."""
+    """One nb_ctx: `n` particles resident on one MI355X, state kept as SoA in HBM between calls.
+    `devices=[d0, d1, ...]` spreads the sinks over several GPUs of the node inside ONE process (nb_create_multi: sink decomposition,
+    peer pulls of the source blocks over xGMI, see include/nbody_amd.h); the same calls then take and return GLOBAL arrays. The
+    one-process-per-GPU path over RCCL is `ShardedEngine` (dist.py)."""
 
-    def __init__(self, n: int, dtype=np.float32, device: int = 0):
+    def __init__(self, n: int, dtype=np.float32, device: int = 0, devices=None):
         self._lib = _lib.load()
         self.n, self.dtype, self.device = int(n), np.dtype(dtype), int(device)
         self._ctx = C.c_void_p()
-        rc = self._lib.nb_create(C.byref(self._ctx), self.n, _code(self.dtype), self.device)
+        if devices is None:
+            self.devices = [self.device]
+            rc = self._lib.nb_create(C.byref(self._ctx), self.n, _code(self.dtype), self.device)
+            what = "nb_create"
+        else:
+            self.devices = [int(d) for d in devices]
+            ids = (C.c_int * len(self.devices))(*self.devices)
+            rc = self._lib.nb_create_multi(C.byref(self._ctx), self.n, _code(self.dtype), len(self.devices), ids)
+            what = "nb_create_multi"
         if rc != _lib.NB_OK:
             self._ctx = C.c_void_p()
-            _lib.check(None, rc, "nb_create")
+            _lib.check(None, rc, what)
+
+    def layout(self):
+        """(counts, offsets) of the contiguous sink ranges owned by the context's devices."""
+        cap = 64
+        cnt, off = (C.c_int64 * cap)(), (C.c_int64 * cap)()
+        p = self._lib.nb_multi_layout(self._ctx, cnt, off, cap)
+        return list(cnt[:p]), list(off[:p])
 
     # -- lifetime -------------------------------------------------------------------------------
     def close(self) -> None:

@@ -257,14 +257,18 @@ int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float
   constexpr int TILE = 512;
   // sinks per lane: 8 (four packed pairs) as soon as there are enough sinks to fill lanes; measured on MI355X
   // (profiles/r01_tune_f32.txt) KS=8/U=2 with many source splits is fastest from N = 2^14 to 2^20.
-  int ks = env_int("NB_F32_KS", 0);
+  static const int env_ks = env_int("NB_F32_KS", 0), env_split = env_int("NB_F32_SPLIT", 0);   // tuning knobs, read once per process
+  int ks = env_ks;
   if (ks != 2 && ks != 4 && ks != 8) ks = n_snk >= 16384 ? 8 : (n_snk >= 4096 ? 4 : 2);
   const int spb = BLOCK * ks;
   const int nblk = (int)((n_snk + spb - 1) / spb);
   // split the source range so that the grid has ~16 blocks per CU (256 CUs) when sinks alone cannot
-  int nsplit = env_int("NB_F32_SPLIT", 0);
+  int nsplit = env_split;
   const int ntiles_total = (int)((n_src + TILE - 1) / TILE);
   if (nsplit <= 0) {
+    // ~4096 blocks (8 rounds of the 512 resident KS = 8 blocks): measured A/B at N = 2^20 (profiles/r02_f32_split_sweep.txt) — no split
+    // (512 blocks = exactly one round) 238.8 ms, 2-way 232.1, 4-way 228.7, 8-way 227.2: blocks of one round do not finish together, later
+    // rounds fill the gaps. The price is an fp64 slab [split][3][N] written and re-read once (0.4 GB at N = 2^20 = 0.07 ms).
     const int target_blocks = 4096;
     nsplit = nblk >= target_blocks ? 1 : (target_blocks + nblk - 1) / nblk;
   }

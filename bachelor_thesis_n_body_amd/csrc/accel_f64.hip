@@ -195,12 +195,13 @@ int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const dou
   const bool uniform = (flags & NB_UNIFORM_MASS) != 0 && n_src > 0;    // one multiply fewer per interaction (15 + seed instead of 16)
   if (n_snk >= (1ll << 31) || n_src >= (1ll << 31)) return nb_fail(c, NB_ERR_ARG, "n must be < 2^31");
   constexpr int TILE = 256;
-  int ks = env_int("NB_F64_KS", 0);
+  static const int env_ks = env_int("NB_F64_KS", 0), env_rsq = env_int("NB_F64_RSQ", 0), env_split = env_int("NB_F64_SPLIT", 0);   // read once
+  int ks = env_ks;
   if (ks != 1 && ks != 2 && ks != 4) ks = n_snk >= 32768 ? 4 : (n_snk >= 8192 ? 2 : 1);
-  const int rsq_mode = env_int("NB_F64_RSQ", 0);
+  const int rsq_mode = env_rsq;
   const int spb = BLOCK * ks;
   const int nblk = (int)((n_snk + spb - 1) / spb);
-  int nsplit = env_int("NB_F64_SPLIT", 0);
+  int nsplit = env_split;
   const int ntiles_total = (int)((n_src + TILE - 1) / TILE);
   if (nsplit <= 0) nsplit = nblk >= 4096 ? 1 : (4096 + nblk - 1) / nblk;
   if (nsplit > ntiles_total) nsplit = ntiles_total > 0 ? ntiles_total : 1;

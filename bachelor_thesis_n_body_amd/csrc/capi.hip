@@ -89,8 +89,43 @@ int nb_create(nb_ctx** out, int64_t n, int dtype, int device) {
   return NB_OK;
 }
 
+int nb_create_multi(nb_ctx** out, int64_t n, int dtype, int ndev, const int* dev_ids) {
+  if (!out) return nb_fail(nullptr, NB_ERR_ARG, "nb_create_multi: out is NULL");
+  *out = nullptr;
+  if (ndev < 1 || ndev > 64 || !dev_ids) return nb_fail(nullptr, NB_ERR_ARG, "nb_create_multi: ndev must be in [1, 64] and dev_ids non-NULL");
+  if (n < ndev) return nb_fail(nullptr, NB_ERR_ARG, "nb_create_multi: fewer particles than devices");
+  if (n >= (1ll << 31)) return nb_fail(nullptr, NB_ERR_ARG, "nb_create_multi: n must be < 2^31");
+  if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(nullptr, NB_ERR_ARG, "nb_create_multi: dtype must be NB_F32 or NB_F64");
+  int visible = 0;
+  hipError_t e = hipGetDeviceCount(&visible);
+  if (e != hipSuccess || visible <= 0)
+    return nb_fail(nullptr, NB_ERR_NODEVICE, std::string("nb_create_multi: no HIP device visible (") + hipGetErrorString(e) + ")");
+  for (int g = 0; g < ndev; ++g)
+    if (dev_ids[g] < 0 || dev_ids[g] >= visible) return nb_fail(nullptr, NB_ERR_NODEVICE, "nb_create_multi: device index out of range");
+  nb_ctx* c = new (std::nothrow) nb_ctx();
+  if (!c) return nb_fail(nullptr, NB_ERR_ARG, "nb_create_multi: out of host memory");
+  c->device = dev_ids[0]; c->dtype = dtype; c->n = n;
+  int rc = nb_multi_create(c, ndev, dev_ids);
+  if (rc) { g_create_err = c->err; nb_multi_release(c); delete c; return rc; }
+  *out = c;
+  return NB_OK;
+}
+
+int nb_multi_layout(const nb_ctx* c, int64_t* counts, int64_t* offsets, int cap) {
+  if (!c) return NB_ERR_ARG;
+  if (!c->multi) { if (cap > 0) { if (counts) counts[0] = c->n; if (offsets) offsets[0] = 0; } return 1; }
+  if (counts) nb_multi_info(c, 0, counts, cap);
+  if (offsets) nb_multi_info(c, 1, offsets, cap);
+  int64_t dummy[64];
+  return nb_multi_info(c, 2, dummy, 64);
+}
+
+// entry points that only make sense on one device
+#define NB_SINGLE_ONLY(c, name) do { if ((c)->multi) return nb_fail((c), NB_ERR_ARG, name ": not available on a multi-device context (direct solver, host-pointer surface only)"); } while (0)
+
 int nb_destroy(nb_ctx* c) {
   if (!c) return NB_OK;
+  if (c->multi) { nb_multi_release(c); delete c; return NB_OK; }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
@@ -107,8 +142,11 @@ int nb_destroy(nb_ctx* c) {
   return NB_OK;
 }
 
+// The handle is BORROWED: the context enqueues on it and synchronises it (nb_synchronize, nb_destroy, the next nb_set_stream, scratch
+// growth), so the caller must keep the stream alive until the next nb_set_stream or nb_destroy (include/nbody_amd.h).
 int nb_set_stream(nb_ctx* c, void* hip_stream) {
   if (!c) return NB_ERR_ARG;
+  NB_SINGLE_ONLY(c, "nb_set_stream");
   int rc = use_device(c); if (rc) return rc;
   NB_HIP(c, hipStreamSynchronize(c->stream));
   if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
@@ -120,6 +158,8 @@ int nb_set_stream(nb_ctx* c, void* hip_stream) {
 
 int nb_set_solver(nb_ctx* c, int solver, double theta) {
   if (!c) return NB_ERR_ARG;
+  if (c->multi && solver != NB_SOLVER_DIRECT) NB_SINGLE_ONLY(c, "nb_set_solver(tree)");
+  if (c->multi) return NB_OK;
   if (solver != NB_SOLVER_DIRECT && solver != NB_SOLVER_TREE) return nb_fail(c, NB_ERR_ARG, "nb_set_solver: unknown solver (use nb_set_periodic for Ewald)");
   if (solver == NB_SOLVER_TREE && c->dtype != NB_F32) return nb_fail(c, NB_ERR_ARG, "nb_set_solver: the tree solver is fp32 only");
   if (solver == NB_SOLVER_TREE && !(theta >= 0.0 && theta < 2.0)) return nb_fail(c, NB_ERR_ARG, "nb_set_solver: theta must be in [0, 2)");
@@ -130,6 +170,7 @@ int nb_set_solver(nb_ctx* c, int solver, double theta) {
 
 int nb_set_periodic(nb_ctx* c, double boxsize, double alpha_L, int kmax) {
   if (!c) return NB_ERR_ARG;
+  NB_SINGLE_ONLY(c, "nb_set_periodic");
   if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
   c->acc_valid = false;
   if (!(boxsize > 0.0)) { c->solver = NB_SOLVER_DIRECT; c->box = 0.0; return NB_OK; }
@@ -140,6 +181,7 @@ int nb_set_periodic(nb_ctx* c, double boxsize, double alpha_L, int kmax) {
 
 int nb_set_mesh(nb_ctx* c, int solver, double boxsize, int ngrid, double scale_cells, double range_scales, int flags) {
   if (!c) return NB_ERR_ARG;
+  NB_SINGLE_ONLY(c, "nb_set_mesh");
   if (solver != NB_SOLVER_PM && solver != NB_SOLVER_P3M) return nb_fail(c, NB_ERR_ARG, "nb_set_mesh: solver must be NB_SOLVER_PM or NB_SOLVER_P3M");
   if (!(boxsize > 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_set_mesh: boxsize must be > 0");
   if (ngrid < 4 || ngrid > 2048) return nb_fail(c, NB_ERR_ARG, "nb_set_mesh: grid size must be in [4, 2048]");
@@ -158,6 +200,7 @@ int nb_set_mesh(nb_ctx* c, int solver, double boxsize, int ngrid, double scale_c
 
 int nb_synchronize(nb_ctx* c) {
   if (!c) return NB_ERR_ARG;
+  if (c->multi) return nb_multi_sync(c);
   int rc = use_device(c); if (rc) return rc;
   NB_HIP(c, hipStreamSynchronize(c->stream));
   return NB_OK;
@@ -167,6 +210,7 @@ int nb_set_state(nb_ctx* c, const void* x, const void* y, const void* z, const v
                  const void* vz, const void* m) {
   if (!c) return NB_ERR_ARG;
   if (!x || !y || !z || !vx || !vy || !vz || !m) return nb_fail(c, NB_ERR_ARG, "nb_set_state: NULL array");
+  if (c->multi) return nb_multi_set_state(c, x, y, z, vx, vy, vz, m);
   int rc = use_device(c); if (rc) return rc;
   const size_t b = (size_t)c->n * esize(c->dtype);
   char* base = reinterpret_cast<char*>(c->state);
@@ -188,6 +232,7 @@ int nb_set_state(nb_ctx* c, const void* x, const void* y, const void* z, const v
 int nb_get_state(nb_ctx* c, void* x, void* y, void* z, void* vx, void* vy, void* vz, void* m) {
   if (!c) return NB_ERR_ARG;
   if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_get_state: no state set");
+  if (c->multi) { void* dst[7] = {x, y, z, m, vx, vy, vz}; const int f[7] = {0, 1, 2, 3, 4, 5, 6}; return nb_multi_get(c, dst, f, 7); }
   int rc = use_device(c); if (rc) return rc;
   const size_t b = (size_t)c->n * esize(c->dtype);
   char* base = reinterpret_cast<char*>(c->state);
@@ -239,6 +284,11 @@ int nb_accel(nb_ctx* c, double eps, double G, void* ax, void* ay, void* az) {
   if (!c) return NB_ERR_ARG;
   if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_accel: call nb_set_state first");
   if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_accel: eps must be >= 0");
+  if (c->multi) {
+    int rcm = nb_multi_accel(c, eps, G); if (rcm) return rcm;
+    void* dst[3] = {ax, ay, az}; const int f[3] = {7, 8, 9};
+    return nb_multi_get(c, dst, f, 3);
+  }
   int rc = use_device(c); if (rc) return rc;
   rc = refresh_acc(c, eps, G); if (rc) return rc;
   const size_t b = (size_t)c->n * esize(c->dtype);
@@ -252,6 +302,11 @@ int nb_accel(nb_ctx* c, double eps, double G, void* ax, void* ay, void* az) {
 
 int nb_get_acc(nb_ctx* c, void* ax, void* ay, void* az) {
   if (!c) return NB_ERR_ARG;
+  if (c->multi) {
+    if (!c->has_state || !nb_multi_has_acc(c)) return nb_fail(c, NB_ERR_STATE, "nb_get_acc: no cached acceleration (call nb_accel or nb_step first)");
+    void* dst[3] = {ax, ay, az}; const int f[3] = {7, 8, 9};
+    return nb_multi_get(c, dst, f, 3);
+  }
   if (!c->has_state || !c->acc_valid) return nb_fail(c, NB_ERR_STATE, "nb_get_acc: no cached acceleration (call nb_accel or nb_step first)");
   int rc = use_device(c); if (rc) return rc;
   const size_t b = (size_t)c->n * esize(c->dtype);
@@ -269,6 +324,10 @@ int nb_step(nb_ctx* c, double dt, int64_t nsteps, double eps, double G) {
   if (nsteps < 0) return nb_fail(c, NB_ERR_ARG, "nb_step: nsteps must be >= 0");
   if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_step: eps must be >= 0");
   if (nsteps == 0) return NB_OK;
+  if (c->multi) {
+    std::vector<double> kh((size_t)nsteps, 0.5 * dt), dr((size_t)nsteps, dt);
+    return nb_multi_kdk(c, nsteps, kh.data(), dr.data(), kh.data(), eps, G);
+  }
   int rc = use_device(c); if (rc) return rc;
   if (!c->acc_valid || c->acc_eps != eps || c->acc_G != G) { rc = refresh_acc(c, eps, G); if (rc) return rc; }
   const size_t b = (size_t)c->n * esize(c->dtype);
@@ -328,6 +387,7 @@ int nb_kdk_step(nb_ctx* c, double kick1, double drift, double kick2, double eps,
   if (!c) return NB_ERR_ARG;
   if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_kdk_step: call nb_set_state first");
   if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_kdk_step: eps must be >= 0");
+  if (c->multi) return nb_multi_kdk(c, 1, &kick1, &drift, &kick2, eps, G);
   int rc = use_device(c); if (rc) return rc;
   if (!c->acc_valid || c->acc_eps != eps || c->acc_G != G) { rc = refresh_acc(c, eps, G); if (rc) return rc; }
   rc = kdk_enqueue(c, kick1, drift, kick2, eps, G); if (rc) return rc;
@@ -341,6 +401,7 @@ int nb_kdk_run(nb_ctx* c, int64_t nsteps, const double* kick1, const double* dri
   if (nsteps < 0 || (nsteps > 0 && (!kick1 || !drift || !kick2))) return nb_fail(c, NB_ERR_ARG, "nb_kdk_run: bad step arrays");
   if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_kdk_run: eps must be >= 0");
   if (nsteps == 0) return NB_OK;
+  if (c->multi) return nb_multi_kdk(c, nsteps, kick1, drift, kick2, eps, G);
   int rc = use_device(c); if (rc) return rc;
   if (!c->acc_valid || c->acc_eps != eps || c->acc_G != G) { rc = refresh_acc(c, eps, G); if (rc) return rc; }
   for (int64_t k = 0; k < nsteps; ++k) { rc = kdk_enqueue(c, kick1[k], drift[k], kick2[k], eps, G); if (rc) return rc; }
@@ -352,6 +413,7 @@ int nb_energy(nb_ctx* c, double eps, double G, double* kinetic, double* potentia
   if (!c) return NB_ERR_ARG;
   if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_energy: call nb_set_state first");
   if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_energy: eps must be >= 0");
+  if (c->multi) return nb_multi_energy(c, eps, G, kinetic, potential);
   int rc = use_device(c); if (rc) return rc;
   const size_t b = (size_t)c->n * esize(c->dtype);
   char* s = reinterpret_cast<char*>(c->state);
@@ -380,6 +442,7 @@ int nb_step_energy(nb_ctx* c, double dt, int64_t nsteps, double eps, double G, d
   if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_step_energy: call nb_set_state first");
   if (nsteps < 0) return nb_fail(c, NB_ERR_ARG, "nb_step_energy: nsteps must be >= 0");
   if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_step_energy: eps must be >= 0");
+  NB_SINGLE_ONLY(c, "nb_step_energy");
   if (c->solver != NB_SOLVER_DIRECT) return nb_fail(c, NB_ERR_ARG, "nb_step_energy: direct solver only");
   if (nsteps == 0) return NB_OK;
   int rc = use_device(c); if (rc) return rc;
@@ -420,6 +483,7 @@ int nb_accel_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const voi
                  const void* xs, const void* ys, const void* zs, const void* ms, int64_t n_src,
                  double eps, double G, void* ax, void* ay, void* az, int flags) {
   if (!c) return NB_ERR_ARG;
+  NB_SINGLE_ONLY(c, "nb_accel_dev");
   if (n_snk < 0 || n_src < 0) return nb_fail(c, NB_ERR_ARG, "nb_accel_dev: negative count");
   if (n_snk > 0 && (!xi || !yi || !zi || !ax || !ay || !az)) return nb_fail(c, NB_ERR_ARG, "nb_accel_dev: NULL sink array");
   if (n_src > 0 && (!xs || !ys || !zs || !ms)) return nb_fail(c, NB_ERR_ARG, "nb_accel_dev: NULL source array");
@@ -440,6 +504,7 @@ int nb_accel_pot_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const
                      const void* xs, const void* ys, const void* zs, const void* ms, int64_t n_src,
                      double eps, double G, void* ax, void* ay, void* az, double* phi, int flags) {
   if (!c) return NB_ERR_ARG;
+  NB_SINGLE_ONLY(c, "nb_accel_pot_dev");
   if (n_snk < 0 || n_src < 0) return nb_fail(c, NB_ERR_ARG, "nb_accel_pot_dev: negative count");
   if (n_snk > 0 && (!xi || !yi || !zi || !ax || !ay || !az || !phi)) return nb_fail(c, NB_ERR_ARG, "nb_accel_pot_dev: NULL sink array");
   if (n_src > 0 && (!xs || !ys || !zs || !ms)) return nb_fail(c, NB_ERR_ARG, "nb_accel_pot_dev: NULL source array");
@@ -458,6 +523,7 @@ int nb_accel_pot_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const
 
 int nb_pot_energy_dev(nb_ctx* c, int dtype, const double* phi, const void* m, int64_t n, double eps, int uniform, double* w_out) {
   if (!c) return NB_ERR_ARG;
+  NB_SINGLE_ONLY(c, "nb_pot_energy_dev");
   if (!phi || !m || !w_out || n < 0) return nb_fail(c, NB_ERR_ARG, "nb_pot_energy_dev: bad argument");
   if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_pot_energy_dev: unknown dtype");
   if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_pot_energy_dev: eps must be >= 0");
@@ -469,6 +535,7 @@ int nb_potential_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const
                      int64_t n_snk, int64_t snk_global0, const void* xs, const void* ys, const void* zs,
                      const void* ms, int64_t n_src, int64_t src_global0, double eps, double* u_out, int accumulate) {
   if (!c) return NB_ERR_ARG;
+  NB_SINGLE_ONLY(c, "nb_potential_dev");
   if (!u_out) return nb_fail(c, NB_ERR_ARG, "nb_potential_dev: u_out is NULL");
   if (n_snk < 0 || n_src < 0) return nb_fail(c, NB_ERR_ARG, "nb_potential_dev: negative count");
   if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_potential_dev: eps must be >= 0");
@@ -487,6 +554,7 @@ int nb_potential_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const
 int nb_kinetic_dev(nb_ctx* c, int dtype, const void* vx, const void* vy, const void* vz, const void* m, int64_t n,
                    double* k_out) {
   if (!c) return NB_ERR_ARG;
+  NB_SINGLE_ONLY(c, "nb_kinetic_dev");
   if (!k_out || n < 0) return nb_fail(c, NB_ERR_ARG, "nb_kinetic_dev: bad argument");
   if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_kinetic_dev: unknown dtype");
   int rc = use_device(c); if (rc) return rc;
@@ -496,6 +564,7 @@ int nb_kinetic_dev(nb_ctx* c, int dtype, const void* vx, const void* vy, const v
 int nb_kick_dev(nb_ctx* c, int dtype, void* vx, void* vy, void* vz, const void* ax, const void* ay, const void* az,
                 int64_t n, double h) {
   if (!c) return NB_ERR_ARG;
+  NB_SINGLE_ONLY(c, "nb_kick_dev");
   if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_kick_dev: unknown dtype");
   int rc = use_device(c); if (rc) return rc;
   return nb_launch_kick(c, dtype, vx, vy, vz, ax, ay, az, n, h);
@@ -504,6 +573,7 @@ int nb_kick_dev(nb_ctx* c, int dtype, void* vx, void* vy, void* vz, const void* 
 int nb_drift_dev(nb_ctx* c, int dtype, void* x, void* y, void* z, const void* vx, const void* vy, const void* vz,
                  int64_t n, double dt) {
   if (!c) return NB_ERR_ARG;
+  NB_SINGLE_ONLY(c, "nb_drift_dev");
   if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_drift_dev: unknown dtype");
   int rc = use_device(c); if (rc) return rc;
   return nb_launch_drift(c, dtype, x, y, z, vx, vy, vz, n, dt);

@@ -1,0 +1,308 @@
+// Multi-device context of the C-ABI ("nb_create(..., ndev, dev_ids)", §8e sink decomposition) — nb_create_multi.
+//
+// One host thread drives ndev GPUs of one node. Device g owns the contiguous sink range [off_g, off_g + cnt_g) as an ordinary
+// single-device context (its own stream, SoA state, scratch) and integrates only those particles. Every device needs ALL
+// sources: at each force evaluation it PULLS the (x,y,z,m) block of every other owner straight out of that owner's state with
+// hipMemcpyPeerAsync on a copy stream — one contiguous 16*cnt (fp32) / 32*cnt (fp64) byte message per owner — while its force
+// kernel works on the block that arrived before (two receive buffers). At hop h device g reads owner (g + h) mod P, so in every hop
+// each device is read by exactly one other: on the fully connected xGMI mesh of an MI355X node the P pulls of a hop run on P
+// different links (a ring that forwards blocks would use one link per device). Accelerations need no reduction — each sink's
+// sum completes locally, chunk by chunk (NB_ACCUMULATE); energies are summed on the host from P device scalars.
+//
+// Ordering, all by events (no host synchronisation inside a step):
+//   ev_pos[o]      recorded on owner o's stream when its positions are final          -> a pull of o's block waits for it
+//   ev_copy[g][b]  recorded on g's copy stream after the pull into receive buffer b    -> the kernel reading b waits for it
+//   ev_kern[g][b]  recorded on g's stream after the kernel that read buffer b          -> the next pull into b waits for it
+//   ev_pulled[o][g] recorded on g's copy stream after pulling o's block                -> o's next drift waits for all of them
+// The same device may appear several times in dev_ids (a one-GPU rehearsal of the P-device schedule: tests/test_gpu_multi.py).
+#include "nb_common.h"
+#include "../../include/nbody_amd.h"
+#include <vector>
+
+struct nb_multi_state {
+  int P = 0;
+  std::vector<int> dev;
+  std::vector<nb_ctx*> shard;
+  std::vector<int64_t> cnt, off;
+  int64_t n_max = 0;
+  std::vector<void*> recv0, recv1;                    // two receive buffers of 4 * n_max elements per device
+  std::vector<hipStream_t> copy;                      // per-device copy stream
+  std::vector<hipEvent_t> ev_pos;                     // [P]
+  std::vector<hipEvent_t> ev_copy, ev_kern;           // [P][2]
+  std::vector<hipEvent_t> ev_pulled;                  // [owner][reader]
+  std::vector<char> kern_valid;                       // ev_kern[g][b] has been recorded (also by an EARLIER force evaluation)
+  std::vector<char> pulled_valid;                     // ev_pulled[o][g] has been recorded since o's positions last changed
+  bool uniform = false;
+  bool acc_valid = false;
+  double acc_eps = -1.0, acc_G = 0.0;
+};
+
+namespace {
+
+inline size_t esz(int dtype) { return dtype == NB_F64 ? 8 : 4; }
+
+#define MHIP(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  return nb_fail((c), NB_ERR_HIP, std::string("multi: ") + #call + ": " + hipGetErrorString(e_)); } while (0)
+
+inline char* field_ptr(nb_ctx* s, int field) { return reinterpret_cast<char*>(s->state) + (size_t)field * (size_t)s->n * esz(s->dtype); }
+
+// fn(g, owner, src_base, first): src_base = device pointer on device g to the owner's [x | y | z | m] block (cnt[owner] elements each)
+template <typename F>
+int for_each_chunk(nb_ctx* c, F fn) {
+  nb_multi_state& m = *c->multi;
+  const int P = m.P;
+  const size_t es = esz(c->dtype);
+  for (int g = 0; g < P; ++g) {
+    MHIP(c, hipSetDevice(m.dev[g]));
+    MHIP(c, hipEventRecord(m.ev_pos[g], m.shard[g]->stream));
+  }
+  for (int h = 0; h < P; ++h) {
+    for (int g = 0; g < P; ++g) {
+      MHIP(c, hipSetDevice(m.dev[g]));
+      nb_ctx* s = m.shard[g];
+      if (h + 1 < P) {                                   // pull the block of hop h+1 while hop h computes
+        const int o2 = (g + h + 1) % P, b = (h + 1) & 1;
+        void* dst = b ? m.recv1[g] : m.recv0[g];
+        MHIP(c, hipStreamWaitEvent(m.copy[g], m.ev_pos[o2], 0));
+        // the last kernel that read this buffer (hop h-1, or the tail of the PREVIOUS evaluation) must be done with it
+        if (m.kern_valid[g * 2 + b]) MHIP(c, hipStreamWaitEvent(m.copy[g], m.ev_kern[g * 2 + b], 0));
+        MHIP(c, hipMemcpyPeerAsync(dst, m.dev[g], m.shard[o2]->state, m.dev[o2], 4 * (size_t)m.cnt[o2] * es, m.copy[g]));
+        MHIP(c, hipEventRecord(m.ev_copy[g * 2 + b], m.copy[g]));
+        MHIP(c, hipEventRecord(m.ev_pulled[o2 * P + g], m.copy[g]));
+        m.pulled_valid[o2 * P + g] = 1;
+      }
+      const int o = (g + h) % P, b = h & 1;
+      const void* src = h == 0 ? s->state : (b ? m.recv1[g] : m.recv0[g]);
+      if (h >= 1) MHIP(c, hipStreamWaitEvent(s->stream, m.ev_copy[g * 2 + b], 0));
+      int rc = fn(g, o, reinterpret_cast<const char*>(src), h == 0);
+      if (rc) return nb_fail(c, rc, std::string("multi: device ") + std::to_string(m.dev[g]) + ": " + s->err);
+      if (h >= 1) { MHIP(c, hipEventRecord(m.ev_kern[g * 2 + b], s->stream)); m.kern_valid[g * 2 + b] = 1; }
+    }
+  }
+  return NB_OK;
+}
+
+// owner o is about to change its positions: every pull of its block must have finished
+int wait_for_readers(nb_ctx* c, int o) {
+  nb_multi_state& m = *c->multi;
+  for (int g = 0; g < m.P; ++g)
+    if (g != o && m.pulled_valid[o * m.P + g]) {
+      MHIP(c, hipStreamWaitEvent(m.shard[o]->stream, m.ev_pulled[o * m.P + g], 0));
+      m.pulled_valid[o * m.P + g] = 0;
+    }
+  return NB_OK;
+}
+
+int refresh_acc(nb_ctx* c, double eps, double G) {
+  nb_multi_state& m = *c->multi;
+  const size_t es = esz(c->dtype);
+  int rc = for_each_chunk(c, [&](int g, int o, const char* src, bool first) -> int {
+    nb_ctx* s = m.shard[g];
+    const size_t so = (size_t)m.cnt[o] * es;
+    const int flags = (first ? 0 : NB_ACCUMULATE) | (m.uniform ? NB_UNIFORM_MASS : 0);
+    if (c->dtype == NB_F32)
+      return nb_launch_accel_f32(s, (const float*)field_ptr(s, 0), (const float*)field_ptr(s, 1), (const float*)field_ptr(s, 2), s->n,
+                                 (const float*)src, (const float*)(src + so), (const float*)(src + 2 * so), (const float*)(src + 3 * so), m.cnt[o],
+                                 (float)(eps * eps), (float)G, (float*)field_ptr(s, 7), (float*)field_ptr(s, 8), (float*)field_ptr(s, 9), flags);
+    return nb_launch_accel_f64(s, (const double*)field_ptr(s, 0), (const double*)field_ptr(s, 1), (const double*)field_ptr(s, 2), s->n,
+                               (const double*)src, (const double*)(src + so), (const double*)(src + 2 * so), (const double*)(src + 3 * so), m.cnt[o],
+                               eps * eps, G, (double*)field_ptr(s, 7), (double*)field_ptr(s, 8), (double*)field_ptr(s, 9), flags);
+  });
+  if (rc) return rc;
+  m.acc_valid = true; m.acc_eps = eps; m.acc_G = G;
+  return NB_OK;
+}
+
+int sync_all(nb_ctx* c) {
+  nb_multi_state& m = *c->multi;
+  for (int g = 0; g < m.P; ++g) {
+    MHIP(c, hipSetDevice(m.dev[g]));
+    MHIP(c, hipStreamSynchronize(m.copy[g]));
+    MHIP(c, hipStreamSynchronize(m.shard[g]->stream));
+  }
+  return NB_OK;
+}
+
+}  // namespace
+
+void nb_multi_release(nb_ctx* c) {
+  nb_multi_state* m = c->multi;
+  if (!m) return;
+  for (int g = 0; g < (int)m->shard.size(); ++g) {
+    (void)hipSetDevice(m->dev[g]);
+    if (g < (int)m->copy.size() && m->copy[g]) { (void)hipStreamSynchronize(m->copy[g]); }
+    if (m->shard[g]) { (void)hipStreamSynchronize(m->shard[g]->stream); }
+  }
+  for (int g = 0; g < (int)m->shard.size(); ++g) {
+    (void)hipSetDevice(m->dev[g]);
+    if (g < (int)m->recv0.size() && m->recv0[g]) (void)hipFree(m->recv0[g]);
+    if (g < (int)m->recv1.size() && m->recv1[g]) (void)hipFree(m->recv1[g]);
+    if (g < (int)m->copy.size() && m->copy[g]) (void)hipStreamDestroy(m->copy[g]);
+    if (g < (int)m->ev_pos.size() && m->ev_pos[g]) (void)hipEventDestroy(m->ev_pos[g]);
+    for (int b = 0; b < 2; ++b) {
+      if (g * 2 + b < (int)m->ev_copy.size() && m->ev_copy[g * 2 + b]) (void)hipEventDestroy(m->ev_copy[g * 2 + b]);
+      if (g * 2 + b < (int)m->ev_kern.size() && m->ev_kern[g * 2 + b]) (void)hipEventDestroy(m->ev_kern[g * 2 + b]);
+    }
+    for (int o = 0; o < m->P; ++o)
+      if (o * m->P + g < (int)m->ev_pulled.size() && m->ev_pulled[o * m->P + g]) (void)hipEventDestroy(m->ev_pulled[o * m->P + g]);
+    if (m->shard[g]) (void)nb_destroy(m->shard[g]);
+  }
+  delete m;
+  c->multi = nullptr;
+}
+
+int nb_multi_create(nb_ctx* c, int ndev, const int* dev_ids) {
+  nb_multi_state* m = new nb_multi_state();
+  c->multi = m;
+  m->P = ndev;
+  m->dev.assign(dev_ids, dev_ids + ndev);
+  m->shard.assign(ndev, nullptr);
+  m->cnt.resize(ndev); m->off.resize(ndev);
+  const int64_t base = c->n / ndev, rem = c->n % ndev;          // the first n % P devices own one more particle (dist.partition)
+  for (int g = 0; g < ndev; ++g) { m->cnt[g] = base + (g < rem ? 1 : 0); m->off[g] = g ? m->off[g - 1] + m->cnt[g - 1] : 0; }
+  m->n_max = m->cnt[0];
+  m->recv0.assign(ndev, nullptr); m->recv1.assign(ndev, nullptr); m->copy.assign(ndev, nullptr);
+  m->ev_pos.assign(ndev, nullptr); m->ev_copy.assign(2 * ndev, nullptr); m->ev_kern.assign(2 * ndev, nullptr);
+  m->ev_pulled.assign((size_t)ndev * ndev, nullptr); m->pulled_valid.assign((size_t)ndev * ndev, 0); m->kern_valid.assign(2 * (size_t)ndev, 0);
+  const size_t es = esz(c->dtype);
+  for (int g = 0; g < ndev; ++g) {
+    int rc = nb_create(&m->shard[g], m->cnt[g], c->dtype, dev_ids[g]);
+    if (rc) return nb_fail(c, rc, std::string("nb_create_multi: device ") + std::to_string(dev_ids[g]) + ": " + nb_last_error(nullptr));
+    MHIP(c, hipSetDevice(dev_ids[g]));
+    if (ndev > 1) {
+      MHIP(c, hipMalloc(&m->recv0[g], 4 * (size_t)m->n_max * es));
+      MHIP(c, hipMalloc(&m->recv1[g], 4 * (size_t)m->n_max * es));
+    }
+    MHIP(c, hipStreamCreateWithFlags(&m->copy[g], hipStreamNonBlocking));
+    MHIP(c, hipEventCreateWithFlags(&m->ev_pos[g], hipEventDisableTiming));
+    for (int b = 0; b < 2; ++b) {
+      MHIP(c, hipEventCreateWithFlags(&m->ev_copy[g * 2 + b], hipEventDisableTiming));
+      MHIP(c, hipEventCreateWithFlags(&m->ev_kern[g * 2 + b], hipEventDisableTiming));
+    }
+    for (int o = 0; o < ndev; ++o) MHIP(c, hipEventCreateWithFlags(&m->ev_pulled[o * ndev + g], hipEventDisableTiming));
+    for (int o = 0; o < ndev; ++o)                       // direct peer reads over xGMI where the devices differ
+      if (dev_ids[o] != dev_ids[g]) {
+        int can = 0;
+        MHIP(c, hipDeviceCanAccessPeer(&can, dev_ids[g], dev_ids[o]));
+        if (can) {
+          hipError_t e = hipDeviceEnablePeerAccess(dev_ids[o], 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return nb_fail(c, NB_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+          (void)hipGetLastError();
+        }
+      }
+  }
+  return NB_OK;
+}
+
+int nb_multi_set_state(nb_ctx* c, const void* x, const void* y, const void* z, const void* vx, const void* vy, const void* vz, const void* mm) {
+  nb_multi_state& m = *c->multi;
+  const size_t es = esz(c->dtype);
+  int rc = sync_all(c); if (rc) return rc;
+  for (int g = 0; g < m.P; ++g) {
+    const size_t o = (size_t)m.off[g] * es;
+    rc = nb_set_state(m.shard[g], (const char*)x + o, (const char*)y + o, (const char*)z + o, (const char*)vx + o, (const char*)vy + o,
+                      (const char*)vz + o, (const char*)mm + o);
+    if (rc) return nb_fail(c, rc, m.shard[g]->err);
+  }
+  bool uni = true;                                       // equal masses over the WHOLE system (every shard alone is not enough)
+  if (c->dtype == NB_F32) { const float* q = (const float*)mm; for (int64_t i = 1; i < c->n && uni; ++i) uni = q[i] == q[0]; }
+  else { const double* q = (const double*)mm; for (int64_t i = 1; i < c->n && uni; ++i) uni = q[i] == q[0]; }
+  m.uniform = uni;
+  m.acc_valid = false;
+  std::fill(m.pulled_valid.begin(), m.pulled_valid.end(), 0);
+  c->has_state = true;
+  return NB_OK;
+}
+
+int nb_multi_get(nb_ctx* c, void* const* dst, const int* fields, int nf) {
+  nb_multi_state& m = *c->multi;
+  const size_t es = esz(c->dtype);
+  int rc = sync_all(c); if (rc) return rc;
+  for (int g = 0; g < m.P; ++g) {
+    MHIP(c, hipSetDevice(m.dev[g]));
+    for (int f = 0; f < nf; ++f)
+      if (dst[f]) MHIP(c, hipMemcpyAsync((char*)dst[f] + (size_t)m.off[g] * es, field_ptr(m.shard[g], fields[f]), (size_t)m.cnt[g] * es,
+                                         hipMemcpyDeviceToHost, m.shard[g]->stream));
+  }
+  return sync_all(c);
+}
+
+int nb_multi_accel(nb_ctx* c, double eps, double G) {
+  return refresh_acc(c, eps, G);
+}
+
+bool nb_multi_acc_valid(const nb_ctx* c, double eps, double G) {
+  const nb_multi_state& m = *c->multi;
+  return m.acc_valid && m.acc_eps == eps && m.acc_G == G;
+}
+
+bool nb_multi_has_acc(const nb_ctx* c) { return c->multi->acc_valid; }
+
+int nb_multi_kdk(nb_ctx* c, int64_t nsteps, const double* kick1, const double* drift, const double* kick2, double eps, double G) {
+  nb_multi_state& m = *c->multi;
+  int rc;
+  if (!nb_multi_acc_valid(c, eps, G)) { rc = refresh_acc(c, eps, G); if (rc) return rc; }
+  for (int64_t k = 0; k < nsteps; ++k) {
+    // closing kick of step k-1 fused with the opening kick and the drift of step k (each rounded separately: nb_launch_kick_drift)
+    for (int g = 0; g < m.P; ++g) {
+      MHIP(c, hipSetDevice(m.dev[g]));
+      nb_ctx* s = m.shard[g];
+      rc = wait_for_readers(c, g); if (rc) return rc;
+      rc = nb_launch_kick_drift(s, c->dtype, field_ptr(s, 0), field_ptr(s, 1), field_ptr(s, 2), field_ptr(s, 4), field_ptr(s, 5), field_ptr(s, 6),
+                                field_ptr(s, 7), field_ptr(s, 8), field_ptr(s, 9), s->n, k == 0 ? 0.0 : kick2[k - 1], kick1[k], drift[k]);
+      if (rc) return nb_fail(c, rc, s->err);
+    }
+    rc = refresh_acc(c, eps, G); if (rc) return rc;
+  }
+  for (int g = 0; g < m.P; ++g) {
+    MHIP(c, hipSetDevice(m.dev[g]));
+    nb_ctx* s = m.shard[g];
+    rc = nb_launch_kick(s, c->dtype, field_ptr(s, 4), field_ptr(s, 5), field_ptr(s, 6), field_ptr(s, 7), field_ptr(s, 8), field_ptr(s, 9), s->n, kick2[nsteps - 1]);
+    if (rc) return nb_fail(c, rc, s->err);
+  }
+  return sync_all(c);
+}
+
+int nb_multi_energy(nb_ctx* c, double eps, double G, double* kinetic, double* potential) {
+  nb_multi_state& m = *c->multi;
+  const size_t es = esz(c->dtype);
+  int rc;
+  for (int g = 0; g < m.P; ++g) {
+    MHIP(c, hipSetDevice(m.dev[g]));
+    nb_ctx* s = m.shard[g];
+    rc = nb_launch_kinetic(s, c->dtype, field_ptr(s, 4), field_ptr(s, 5), field_ptr(s, 6), field_ptr(s, 3), s->n, s->scal);
+    if (rc) return nb_fail(c, rc, s->err);
+  }
+  rc = for_each_chunk(c, [&](int g, int o, const char* src, bool first) -> int {
+    nb_ctx* s = m.shard[g];
+    const size_t so = (size_t)m.cnt[o] * es;
+    if (c->dtype == NB_F32)
+      return nb_launch_potential_f32(s, (const float*)field_ptr(s, 0), (const float*)field_ptr(s, 1), (const float*)field_ptr(s, 2), (const float*)field_ptr(s, 3),
+                                     s->n, m.off[g], (const float*)src, (const float*)(src + so), (const float*)(src + 2 * so), (const float*)(src + 3 * so),
+                                     m.cnt[o], m.off[o], (float)(eps * eps), s->scal + 1, first ? 0 : 1);
+    return nb_launch_potential_f64(s, (const double*)field_ptr(s, 0), (const double*)field_ptr(s, 1), (const double*)field_ptr(s, 2), (const double*)field_ptr(s, 3),
+                                   s->n, m.off[g], (const double*)src, (const double*)(src + so), (const double*)(src + 2 * so), (const double*)(src + 3 * so),
+                                   m.cnt[o], m.off[o], eps * eps, s->scal + 1, first ? 0 : 1);
+  });
+  if (rc) return rc;
+  double K = 0.0, W = 0.0;
+  for (int g = 0; g < m.P; ++g) {
+    MHIP(c, hipSetDevice(m.dev[g]));
+    double h[2];
+    MHIP(c, hipMemcpyAsync(h, m.shard[g]->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, m.shard[g]->stream));
+    MHIP(c, hipStreamSynchronize(m.shard[g]->stream));
+    K += h[0]; W += h[1];                                  // fixed order: device 0, 1, ...
+  }
+  rc = sync_all(c); if (rc) return rc;
+  if (kinetic) *kinetic = K;
+  if (potential) *potential = -0.5 * G * W;
+  return NB_OK;
+}
+
+int nb_multi_sync(nb_ctx* c) { return sync_all(c); }
+
+int nb_multi_info(const nb_ctx* c, int which, int64_t* out, int cap) {
+  const nb_multi_state& m = *c->multi;
+  for (int g = 0; g < m.P && g < cap; ++g) out[g] = which == 0 ? m.cnt[g] : (which == 1 ? m.off[g] : (int64_t)m.dev[g]);
+  return m.P;
+}

@@ -8,6 +8,7 @@
 struct nb_bh_state;   // Barnes-Hut buffers (bh.hip)
 struct nb_ewald_state;   // k-vector table and structure factors (ewald.hip)
 struct nb_mesh_state;    // PM / P3M grids, FFT plan and cell lists (mesh.hip)
+struct nb_multi_state;   // per-device shards, receive buffers and events of a multi-device context (multi.hip)
 
 struct nb_ctx {
   int device = 0;
@@ -37,6 +38,7 @@ struct nb_ctx {
   nb_bh_state* bh = nullptr;
   nb_ewald_state* ewald = nullptr;
   nb_mesh_state* mesh = nullptr;
+  nb_multi_state* multi = nullptr;   // non-null: this context drives several devices (nb_create_multi); it owns no device state itself
   int mesh_grid = 0, mesh_interlace = 1, mesh_parts = 3;   // NB_SOLVER_PM / NB_SOLVER_P3M (nb_set_mesh)
   double mesh_scale = 1.25, mesh_range = 4.5;              // r_s in cells, cut-off in r_s
   double box = 0.0, alphaL = 6.2;   // periodic cube edge and Ewald splitting (NB_SOLVER_EWALD)
@@ -77,6 +79,18 @@ int nb_launch_short_range(nb_ctx* c, int dtype, const void* x, const void* y, co
                           double alpha, double rcut, double eps2, double G, void* ax, void* ay, void* az);   // ADDS to acc
 void nb_mesh_release(nb_ctx* c);
 void nb_bh_release(nb_ctx* c);
+// multi-device context (multi.hip): the public entry points of capi.hip forward to these when c->multi is set
+int nb_multi_create(nb_ctx* c, int ndev, const int* dev_ids);
+void nb_multi_release(nb_ctx* c);
+int nb_multi_set_state(nb_ctx* c, const void* x, const void* y, const void* z, const void* vx, const void* vy, const void* vz, const void* m);
+int nb_multi_get(nb_ctx* c, void* const* dst, const int* fields, int nf);   // fields: 0..9 = x y z m vx vy vz ax ay az
+int nb_multi_accel(nb_ctx* c, double eps, double G);
+bool nb_multi_acc_valid(const nb_ctx* c, double eps, double G);
+bool nb_multi_has_acc(const nb_ctx* c);
+int nb_multi_kdk(nb_ctx* c, int64_t nsteps, const double* kick1, const double* drift, const double* kick2, double eps, double G);
+int nb_multi_energy(nb_ctx* c, double eps, double G, double* kinetic, double* potential);
+int nb_multi_sync(nb_ctx* c);
+int nb_multi_info(const nb_ctx* c, int which, int64_t* out, int cap);
 int nb_bh_check(nb_ctx* c);   // call after a stream sync
 int nb_launch_potential_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, const float* mi,
                             int64_t n_snk, int64_t snk_global0, const float* xs, const float* ys, const float* zs,

@@ -43,9 +43,9 @@ PEAK_FP64_VECTOR_TFLOPS = 78.6
 
 def measured_traffic():
     """HBM bytes per accel launch from the committed rocprofv3 PMC passes of THIS command (tools/profile.sh ->
-    profiles/r01_bench_n1_uniform_rocprofv3_summary.txt: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE). bench.py
+    profiles/r02_bench_n1_uniform_rocprofv3_summary.txt: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE). bench.py
     cannot run the profiler around itself, so the number is the profile's, or None if the file is absent."""
-    f = ROOT / "profiles" / "r01_bench_n1_uniform_rocprofv3_summary.txt"
+    f = ROOT / "profiles" / "r02_bench_n1_uniform_rocprofv3_summary.txt"
     try:
         rd = wr = None
         for line in f.read_text().splitlines():
@@ -269,7 +269,7 @@ def main():
                          "flop_per_interaction": FLOP_PER_INTERACTION,
                          "interactions_per_launch": k_inter, "avg_launch_ms": k_ms, "launches_timed": k_count,
                          "traffic": measured_traffic() if (world == 1 and args.n == 1 << 20 and args.dtype == "f32") else None,
-                         "traffic_source": "rocprofv3 PMC pass of this command committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE); algorithmic bytes = 28*N"},
+                         "traffic_source": "NOT measured in this run: HBM bytes per launch from the rocprofv3 --pmc passes of this same command committed as profiles/r02_bench_n1_uniform_rocprofv3_summary.txt (FETCH_SIZE x2 + WRITE_SIZE; 0.4 GB = the fp64 slab of the 8-way source split); algorithmic bytes = 28*N"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(state, eps)

@@ -63,9 +63,23 @@ const char* nb_last_error(const nb_ctx* ctx); /* ctx may be NULL: error of the l
 
 /* lifetime: `n` particles owned (integrated) by this context, on HIP device `device` */
 int nb_create(nb_ctx** out, int64_t n, int dtype, int device);
+/* the same kind of context spread over `ndev` GPUs of one node: device dev_ids[g] owns the g-th contiguous range of
+ * sinks (the first n % ndev devices one particle more) and integrates only those; at every force evaluation each device pulls the
+ * (x,y,z,m) block of every other owner over xGMI (peer copies on a copy stream, overlapped with the kernel on the block before), sums
+ * chunk by chunk, no reduction of accelerations. One host thread drives all devices; nothing synchronises inside nb_step. Supported on
+ * such a context: nb_set_state / nb_get_state / nb_accel / nb_get_acc / nb_step / nb_kdk_step / nb_kdk_run / nb_energy /
+ * nb_synchronize / nb_destroy with GLOBAL host arrays of n elements — results equal the single-device context's up to the summation
+ * order of the chunks. Everything else (tree / periodic / mesh solvers, nb_set_stream, nb_step_energy, the _dev surface) returns
+ * NB_ERR_ARG. A device may be listed more than once (rehearsal of the P-device schedule on one GPU). */
+int nb_create_multi(nb_ctx** out, int64_t n, int dtype, int ndev, const int* dev_ids);
+/* sink ranges of a context: fills counts[g], offsets[g] for g < min(cap, ndev) (either may be NULL), returns ndev (1 for nb_create) */
+int nb_multi_layout(const nb_ctx* ctx, int64_t* counts, int64_t* offsets, int cap);
 int nb_destroy(nb_ctx* ctx);
 /* run all subsequent work on the caller's hipStream_t (e.g. torch's current stream) instead of the private
- * stream created by nb_create; the handle is used as given, NULL being HIP's default (null) stream */
+ * stream created by nb_create; the handle is used as given, NULL being HIP's default (null) stream. The handle is BORROWED: the
+ * context keeps enqueueing on and synchronising it, so it must stay alive until the next nb_set_stream or nb_destroy. On the NULL
+ * stream nb_step cannot use hipGraph replay for small N (HIP's legacy stream cannot be captured): it then launches every step eagerly,
+ * same results, more launch overhead. */
 int nb_set_stream(nb_ctx* ctx, void* hip_stream);
 int nb_synchronize(nb_ctx* ctx);
 /* force solver used by nb_accel / nb_step of this context: NB_SOLVER_DIRECT (O(N^2), default) or NB_SOLVER_TREE =
