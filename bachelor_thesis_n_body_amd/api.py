@@ -90,6 +90,10 @@ class Engine:
         _lib.check(self._ctx, self._lib.nb_kdk_run(self._ctx, k1.size, k1.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
                                                    k2.ctypes.data_as(C.c_void_p), eps, G), "nb_kdk_run")
 
+    def last_run_used_graph(self) -> bool:
+        """True if the last kdk_run() replayed a captured hipGraph of one step (small-N, launch-bound runs)."""
+        return bool(self._lib.nb_last_run_used_graph(self._ctx))
+
     def set_stream(self, hip_stream: int) -> None:
         _lib.check(self._ctx, self._lib.nb_set_stream(self._ctx, C.c_void_p(hip_stream)), "nb_set_stream")
 

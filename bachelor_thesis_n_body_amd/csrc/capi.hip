@@ -404,10 +404,59 @@ int nb_kdk_run(nb_ctx* c, int64_t nsteps, const double* kick1, const double* dri
   if (c->multi) return nb_multi_kdk(c, nsteps, kick1, drift, kick2, eps, G);
   int rc = use_device(c); if (rc) return rc;
   if (!c->acc_valid || c->acc_eps != eps || c->acc_G != G) { rc = refresh_acc(c, eps, G); if (rc) return rc; }
-  for (int64_t k = 0; k < nsteps; ++k) { rc = kdk_enqueue(c, kick1[k], drift[k], kick2[k], eps, G); if (rc) return rc; }
+  // Launch-bound sizes (the 32^3 farm jobs of the thesis: ~100 small launches per P3M step, 1.6 ms per step of which the kernels are a
+  // fraction): step 0 runs eagerly (it sizes every scratch buffer), then ONE step — with its kick/drift factors read from a device table
+  // indexed by a device-side step counter — is captured into a hipGraph and replayed for steps 1..n-1. Any failure to capture (a library
+  // call that does not support stream capture) falls back to the eager loop; results are bit-identical either way.
+  static const bool no_graph = getenv("NB_NO_GRAPH") != nullptr;
+  int64_t k0 = 0;
+  c->graph_replayed = false;
+  if (!no_graph && c->stream != nullptr && c->solver != NB_SOLVER_TREE && c->n <= 300000 && nsteps >= 8) {
+    rc = kdk_enqueue(c, kick1[0], drift[0], kick2[0], eps, G); if (rc) return rc;
+    k0 = 1;
+    std::vector<double> fac((size_t)nsteps * 3);
+    for (int64_t k = 0; k < nsteps; ++k) { fac[3 * k] = kick1[k]; fac[3 * k + 1] = drift[k]; fac[3 * k + 2] = kick2[k]; }
+    double* dfac = nullptr; int* dstep = nullptr;
+    NB_HIP(c, hipMalloc((void**)&dfac, fac.size() * sizeof(double) + 16));
+    dstep = reinterpret_cast<int*>(dfac + fac.size());
+    const int one = 1;
+    hipError_t e = hipMemcpyAsync(dfac, fac.data(), fac.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dstep, &one, sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    bool ok = e == hipSuccess && hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      const size_t b = (size_t)c->n * esize(c->dtype);
+      char* s = reinterpret_cast<char*>(c->state);
+      int rcc = nb_launch_kdk_indexed(c, c->dtype, 0, s, s + b, s + 2 * b, s + 4 * b, s + 5 * b, s + 6 * b, s + 7 * b, s + 8 * b, s + 9 * b, c->n, dfac, dstep);
+      if (!rcc && c->solver >= NB_SOLVER_EWALD) rcc = nb_launch_wrap(c, c->dtype, s, s + b, s + 2 * b, c->n, c->box);
+      if (!rcc) rcc = refresh_acc(c, eps, G);
+      if (!rcc) rcc = nb_launch_kdk_indexed(c, c->dtype, 1, s, s + b, s + 2 * b, s + 4 * b, s + 5 * b, s + 6 * b, s + 7 * b, s + 8 * b, s + 9 * b, c->n, dfac, dstep);
+      const hipError_t ec = hipStreamEndCapture(c->stream, &g);
+      ok = !rcc && ec == hipSuccess && g != nullptr && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
+    }
+    (void)hipGetLastError();                          // a refused capture must not poison the eager fallback
+    if (ok) {
+      for (int64_t k = 1; k < nsteps && ok; ++k) ok = hipGraphLaunch(ge, c->stream) == hipSuccess;
+      if (ok) k0 = nsteps;
+    }
+    if (!ok && k0 == 1) {                             // nothing was replayed: the state is still the one after step 0
+      c->err.clear();
+    }
+    hipError_t es = hipStreamSynchronize(c->stream);
+    if (ge) (void)hipGraphExecDestroy(ge);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipFree(dfac);
+    if (es != hipSuccess) return nb_fail(c, NB_ERR_HIP, std::string("nb_kdk_run (graph replay): ") + hipGetErrorString(es));
+    if (!ok && k0 != 1) return nb_fail(c, NB_ERR_HIP, "nb_kdk_run: hipGraphLaunch failed part-way through the run");
+    c->graph_replayed = ok;
+  }
+  for (int64_t k = k0; k < nsteps; ++k) { rc = kdk_enqueue(c, kick1[k], drift[k], kick2[k], eps, G); if (rc) return rc; }
   NB_HIP(c, hipStreamSynchronize(c->stream));       // the only host round trip of the run
   return nb_bh_check(c);
 }
+
+int nb_last_run_used_graph(const nb_ctx* c) { return c ? (c->graph_replayed ? 1 : 0) : NB_ERR_ARG; }
 
 int nb_energy(nb_ctx* c, double eps, double G, double* kinetic, double* potential) {
   if (!c) return NB_ERR_ARG;

@@ -48,6 +48,35 @@ kick_drift_kernel(T* __restrict__ x, T* __restrict__ y, T* __restrict__ z, T* __
   }
 }
 
+// Generalised KDK step whose factors come from DEVICE memory, indexed by a device-side step counter: the launch sequence of a step is then
+// identical for every step of a run and can be captured once into a hipGraph and replayed (nb_kdk_run on launch-bound sizes).
+//   pre : v += a*kick1[s] ; x += v*drift[s]      post: v += a*kick2[s]      (s = *step; same arithmetic as kick_kernel + drift_kernel)
+template <typename T>
+__global__ void __launch_bounds__(256)
+kdk_pre_kernel(T* __restrict__ x, T* __restrict__ y, T* __restrict__ z, T* __restrict__ vx, T* __restrict__ vy, T* __restrict__ vz,
+               const T* __restrict__ ax, const T* __restrict__ ay, const T* __restrict__ az, int64_t n,
+               const double* __restrict__ fac, const int* __restrict__ step) {
+  const int s = step[0];
+  const T h = (T)fac[3 * s], dt = (T)fac[3 * s + 1];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const T v0 = vx[i] + ax[i] * h, v1 = vy[i] + ay[i] * h, v2 = vz[i] + az[i] * h;
+    vx[i] = v0; vy[i] = v1; vz[i] = v2;
+    x[i] = x[i] + v0 * dt; y[i] = y[i] + v1 * dt; z[i] = z[i] + v2 * dt;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+kdk_post_kernel(T* __restrict__ vx, T* __restrict__ vy, T* __restrict__ vz, const T* __restrict__ ax, const T* __restrict__ ay,
+                const T* __restrict__ az, int64_t n, const double* __restrict__ fac, const int* __restrict__ step) {
+  const T h = (T)fac[3 * step[0] + 2];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    vx[i] = vx[i] + ax[i] * h; vy[i] = vy[i] + ay[i] * h; vz[i] = vz[i] + az[i] * h;
+  }
+}
+
+__global__ void kdk_advance_kernel(int* __restrict__ step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
+
 // per-block fp64 partial of sum m v^2 / 2 -> part[blockIdx.x]; fixed-order final pass below
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -169,6 +198,29 @@ int nb_launch_kick_drift(nb_ctx* c, int dtype, void* x, void* y, void* z, void* 
     kick_drift_kernel<double><<<stream_grid(n), 256, 0, c->stream>>>(
         (double*)x, (double*)y, (double*)z, (double*)vx, (double*)vy, (double*)vz, (const double*)ax,
         (const double*)ay, (const double*)az, n, h1, h2, dt, two);
+  NB_HIP(c, hipGetLastError());
+  return NB_OK;
+}
+
+int nb_launch_kdk_indexed(nb_ctx* c, int dtype, int phase, void* x, void* y, void* z, void* vx, void* vy, void* vz,
+                          const void* ax, const void* ay, const void* az, int64_t n, const double* fac, int* step) {
+  if (n <= 0) return NB_OK;
+  if (phase == 0) {
+    if (dtype == NB_F32)
+      kdk_pre_kernel<float><<<stream_grid(n), 256, 0, c->stream>>>((float*)x, (float*)y, (float*)z, (float*)vx, (float*)vy, (float*)vz,
+                                                                   (const float*)ax, (const float*)ay, (const float*)az, n, fac, step);
+    else
+      kdk_pre_kernel<double><<<stream_grid(n), 256, 0, c->stream>>>((double*)x, (double*)y, (double*)z, (double*)vx, (double*)vy, (double*)vz,
+                                                                    (const double*)ax, (const double*)ay, (const double*)az, n, fac, step);
+  } else {
+    if (dtype == NB_F32)
+      kdk_post_kernel<float><<<stream_grid(n), 256, 0, c->stream>>>((float*)vx, (float*)vy, (float*)vz, (const float*)ax, (const float*)ay,
+                                                                    (const float*)az, n, fac, step);
+    else
+      kdk_post_kernel<double><<<stream_grid(n), 256, 0, c->stream>>>((double*)vx, (double*)vy, (double*)vz, (const double*)ax, (const double*)ay,
+                                                                     (const double*)az, n, fac, step);
+    kdk_advance_kernel<<<1, 64, 0, c->stream>>>(step);
+  }
   NB_HIP(c, hipGetLastError());
   return NB_OK;
 }

@@ -32,6 +32,7 @@ struct nb_ctx {
   // one KDK step [kick_drift(h,h,dt); a(x)] captured as a hipGraph and replayed for launch-bound (small-N) runs
   hipGraphExec_t step_graph = nullptr;
   double graph_dt = 0.0, graph_eps = -1.0, graph_G = 0.0;
+  bool graph_replayed = false;   // the last nb_kdk_run replayed a captured step (diagnostic: nb_last_run_used_graph)
   // force solver used by nb_accel / nb_step: direct summation (default) or Barnes-Hut tree (fp32 only)
   int solver = 0;
   double theta = 0.5;
@@ -111,5 +112,8 @@ int nb_launch_kick(nb_ctx* c, int dtype, void* vx, void* vy, void* vz, const voi
                    const void* az, int64_t n, double h);
 int nb_launch_drift(nb_ctx* c, int dtype, void* x, void* y, void* z, const void* vx, const void* vy,
                     const void* vz, int64_t n, double dt);
+// phase 0: v += a*fac[3s]; x += v*fac[3s+1]   phase 1: v += a*fac[3s+2]; ++s      with s = *step read on the device (graph-replayable KDK)
+int nb_launch_kdk_indexed(nb_ctx* c, int dtype, int phase, void* x, void* y, void* z, void* vx, void* vy, void* vz,
+                          const void* ax, const void* ay, const void* az, int64_t n, const double* fac, int* step);
 int nb_launch_kick_drift(nb_ctx* c, int dtype, void* x, void* y, void* z, void* vx, void* vy, void* vz,
                          const void* ax, const void* ay, const void* az, int64_t n, double h1, double h2, double dt);

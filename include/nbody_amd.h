@@ -110,6 +110,11 @@ int nb_kdk_step(nb_ctx* ctx, double kick1, double drift, double kick2, double ep
 /* nsteps generalised KDK steps with per-step factors (host arrays of nsteps doubles), enqueued back to back: one host
  * synchronisation for the whole run — a comoving run from a_begin to an output time is one call */
 int nb_kdk_run(nb_ctx* ctx, int64_t nsteps, const double* kick1, const double* drift, const double* kick2, double eps, double G);
+/* 1 if the last nb_kdk_run replayed a captured hipGraph of one step (n <= 300 000 particles and >= 8 steps: the launch-bound regime of the
+ * thesis' 32^3 / 64^3 farm jobs — the step's kick/drift factors are read from a device table indexed by a device-side step counter, so every
+ * step is the same launch sequence), 0 if it launched every step eagerly (large n, NB_NO_GRAPH set, the NULL stream, or a capture the
+ * runtime refused). Results are bit-identical either way. */
+int nb_last_run_used_graph(const nb_ctx* ctx);
 
 /* ---- host-pointer surface: the drop-in compute_forces()/step()/energy() (SURVEY §8a ⊕1-⊕3) ---- */
 int nb_set_state(nb_ctx* ctx, const void* x, const void* y, const void* z,

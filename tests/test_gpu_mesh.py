@@ -210,6 +210,39 @@ def test_kdk_run_equals_single_steps(solver):
         e.kdk_run([], [], [], 0.1)                                          # zero steps: nothing happens
 
 
+@pytest.mark.parametrize("solver,dtype", [("p3m", np.float32), ("pm", np.float64), ("ewald", np.float32), ("direct", np.float64)])
+def test_graph_replayed_run_equals_eager_steps(solver, dtype):
+    """>= 8 steps on a small system: nb_kdk_run captures ONE step (factors read from a device table by a device-side step counter) into a
+    hipGraph and replays it — for the mesh solvers that is rocPRIM sorts, hipFFT transforms and ~20 kernels per step. The state must be bit
+    for bit the one of step-by-step eager calls, and the context must report that the graph path was really taken."""
+    L, n, steps = 30.0, 4000, 12
+    pos, m = _cloud(n, L, 18)
+    vel = np.random.default_rng(19).normal(size=(n, 3))
+    s = nb.State(pos.astype(dtype), vel.astype(dtype), m.astype(dtype))
+    k1 = np.linspace(0.01, 0.02, steps); d = np.linspace(0.03, 0.02, steps); k2 = np.linspace(0.015, 0.005, steps)
+    out = []
+    for batched in (True, False):
+        with nb.Engine(n, dtype) as e:
+            if solver in ("p3m", "pm"):
+                e.set_mesh(solver, L, 32)
+            elif solver == "ewald":
+                e.set_periodic(L, 13.2, 15)
+            e.set_state(s)
+            if batched:
+                e.kdk_run(k1, d, k2, 0.1)
+                assert e.last_run_used_graph(), "the graph path was not taken (capture refused?)"
+                e.kdk_run(k1[:3], d[:3], k2[:3], 0.1)                      # < 8 steps: eager, continues from the replayed state
+                assert not e.last_run_used_graph()
+            else:
+                for a, b, c in zip(k1, d, k2):
+                    e.kdk_step(a, b, c, 0.1)
+                for a, b, c in zip(k1[:3], d[:3], k2[:3]):
+                    e.kdk_step(a, b, c, 0.1)
+            out.append(e.get_state())
+    np.testing.assert_array_equal(out[0].pos, out[1].pos)
+    np.testing.assert_array_equal(out[0].vel, out[1].vel)
+
+
 def test_contexts_release_all_device_memory():
     """A farm runs many jobs in one process: creating, using and destroying contexts of every periodic solver must not leak
     device memory (mesh grids, FFT plans, cell lists, tables, structure factors)."""

@@ -94,13 +94,16 @@ def test_multi_context_rejects_what_it_does_not_support_and_bad_arguments():
     bad = (C.c_int * 2)(0, 99)
     assert lib.nb_create_multi(C.byref(ctx), 100, _lib.NB_F32, 2, bad) == -3 and not ctx
     with nb.Engine(1000, np.float32, devices=[0, 0]) as e:
+        with pytest.raises(RuntimeError):
+            e.cached_acc()                                   # no state yet
+        e.set_state(nb.plummer_sphere(1000, 1, np.float32))
         with pytest.raises(RuntimeError, match="multi-device"):
             e.set_solver("tree", 0.5)
         with pytest.raises(RuntimeError, match="multi-device"):
             e.set_periodic(10.0)
         with pytest.raises(RuntimeError, match="multi-device"):
             e.step_with_energy(0.01, 1, 0.01)
-        with pytest.raises(RuntimeError):
-            e.cached_acc()                                   # no state yet
+        with pytest.raises(RuntimeError, match="no cached acceleration"):
+            e.cached_acc()                                   # state, but no force evaluation yet
     with nb.Engine(64, np.float32) as e:                     # a plain context reports one device
         assert e.layout() == ([64], [0])
