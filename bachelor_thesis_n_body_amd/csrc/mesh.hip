@@ -398,7 +398,12 @@ __global__ void __launch_bounds__(64 * SRW)
 short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ keys_s, const int* __restrict__ cell_start,
                    const int* __restrict__ chunk_off, int nrows, int nc, T L, T alpha, T rcut2, T eps2, double G,
                    const uint32_t* __restrict__ idx_s, const float* __restrict__ table, T* __restrict__ ax, T* __restrict__ ay,
-                   T* __restrict__ az) {
+                   T* __restrict__ az, double* __restrict__ part, int64_t n) {
+  // gridDim.y = 1: the wave walks all 9 neighbouring rows and adds its result to ax/ay/az. gridDim.y = 9 * zparts (few chunks: the launch
+  // could not fill the chip, and a lone wave per SIMD crawls through ~7000 sources at one instruction every few cycles — the walk is a chain
+  // of dependent LDS round trips): wave (chunk, blockIdx.y) walks ONE neighbouring row and, of its cells, every zparts-th one, and stores its
+  // partial sums in part[blockIdx.y][3][n] (sorted order); sr_reduce_kernel adds them in a fixed order. (An unrolled branch-free walk was
+  // tried instead and measured slower: without the cut-off vote every candidate pays the full pair arithmetic.)
   // One WAVE per chunk of 64*KS consecutive sorted particles; lane l owns particles l, l+64, ... of the chunk, so each of the KS
   // sink sets is a compact 64-particle blob with its own cut-off vote, while one LDS broadcast of a source serves all KS sets.
   // SRW independent waves share a block only for the look-up table. (PMC of the one-sink-per-lane version: LDS 74 % busy — tile
@@ -433,7 +438,9 @@ short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ k
   double tx[KS], ty[KS], tz[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) { tx[k] = 0.0; ty[k] = 0.0; tz[k] = 0.0; }
-  for (int nb = 0; nb < 9; ++nb) {
+  const int zparts = gridDim.y == 1 ? 1 : (int)gridDim.y / 9, zpart = gridDim.y == 1 ? 0 : (int)blockIdx.y / 9;
+  const int nb_lo = gridDim.y == 1 ? 0 : (int)blockIdx.y % 9, nb_hi = gridDim.y == 1 ? 9 : nb_lo + 1;
+  for (int nb = nb_lo; nb < nb_hi; ++nb) {
     int qx = cx + nb / 3 - 1, qy = cy + nb % 3 - 1;
     T shx = 0, shy = 0;                         // periodic image of the whole neighbour row
     if (qx < 0) { qx += nc; shx = -L; } else if (qx >= nc) { qx -= nc; shx = L; }
@@ -441,7 +448,11 @@ short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ k
     const int qbase = (qx * nc + qy) * nc;
     for (int a = zlo - 1; a <= zhi + 1;) {
       const int img = a < 0 ? -1 : a / nc;                      // which periodic image along z
-      const int b = min(zhi + 1, (img + 1) * nc - 1);           // last cell of this segment
+      int b = min(zhi + 1, (img + 1) * nc - 1);                 // last cell of this segment
+      if (zparts > 1) {                                         // one cell at a time, every zparts-th cell is this wave's
+        b = a;
+        if ((a - (zlo - 1)) % zparts != zpart) { a = b + 1; continue; }
+      }
       const T shz = (T)img * L;
       const int b0 = cell_start[qbase + (a - img * nc)], b1 = cell_start[qbase + (b - img * nc) + 1];
       a = b + 1;
@@ -458,33 +469,33 @@ short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ k
         T fx[KS], fy[KS], fz[KS];
 #pragma unroll
         for (int k = 0; k < KS; ++k) { fx[k] = 0; fy[k] = 0; fz[k] = 0; }
-        for (int e = 0; e < cnt; ++e) {
-          const V4 s = tile[e];                   // wave-uniform address: one LDS broadcast for all KS sink sets
+          for (int e = 0; e < cnt; ++e) {
+            const V4 s = tile[e];                   // wave-uniform address: one LDS broadcast for all KS sink sets
 #pragma unroll
-          for (int k = 0; k < KS; ++k) {
-            const T dx = s.x - me[k].x, dy = s.y - me[k].y, dz = s.z - me[k].z;
-            const T r2 = dx * dx + dy * dy + dz * dz;
-            // wave-uniform branch: the 64 sinks of a set are a compact blob (sub-cell sort), most sources of the walked cells
-            // are out of reach of all of them and cost only the distance test
-            if (__builtin_amdgcn_ballot_w64(r2 < rcut2) != 0) {
-              T pair;
-              if constexpr (TABLE) {
-                const float t = (float)r2 * tscale;
-                const int it = min((int)t, TABN);                  // lanes beyond the cut-off are masked below
-                const float fr = t - (float)it;
-                const float t0 = tab[it], t1 = tab[it + 1];
-                const float sinv = __builtin_amdgcn_rsqf((float)r2 + (float)eps2);
-                const float soft = r2 > (T)0 ? sinv * sinv * sinv : 0.f;
-                pair = soft - fmaf(fr, t1 - t0, t0);
-              } else {
-                pair = sr_factor(r2, eps2, alpha, c2, a2l);
+            for (int k = 0; k < KS; ++k) {
+              const T dx = s.x - me[k].x, dy = s.y - me[k].y, dz = s.z - me[k].z;
+              const T r2 = dx * dx + dy * dy + dz * dz;
+              // wave-uniform branch: the 64 sinks of a set are a compact blob (sub-cell sort), most sources of the walked cells
+              // are out of reach of all of them and cost only the distance test
+              if (__builtin_amdgcn_ballot_w64(r2 < rcut2) != 0) {
+                T pair;
+                if constexpr (TABLE) {
+                  const float t = (float)r2 * tscale;
+                  const int it = min((int)t, TABN);                  // lanes beyond the cut-off are masked below
+                  const float fr = t - (float)it;
+                  const float t0 = tab[it], t1 = tab[it + 1];
+                  const float sinv = __builtin_amdgcn_rsqf((float)r2 + (float)eps2);
+                  const float soft = r2 > (T)0 ? sinv * sinv * sinv : 0.f;
+                  pair = soft - fmaf(fr, t1 - t0, t0);
+                } else {
+                  pair = sr_factor(r2, eps2, alpha, c2, a2l);
+                }
+                T f = s.w * pair;
+                f = r2 < rcut2 ? f : (T)0;
+                fx[k] += f * dx; fy[k] += f * dy; fz[k] += f * dz;
               }
-              T f = s.w * pair;
-              f = r2 < rcut2 ? f : (T)0;
-              fx[k] += f * dx; fy[k] += f * dy; fz[k] += f * dz;
             }
           }
-        }
 #pragma unroll
         for (int k = 0; k < KS; ++k) { tx[k] += (double)fx[k]; ty[k] += (double)fy[k]; tz[k] += (double)fz[k]; }
       }
@@ -494,10 +505,31 @@ short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ k
   for (int k = 0; k < KS; ++k) {
     const int i = i_first + k * 64 + lane;
     if (i <= i_last) {
-      const uint32_t o = idx_s[i];
-      ax[o] += (T)(G * tx[k]); ay[o] += (T)(G * ty[k]); az[o] += (T)(G * tz[k]);
+      if (gridDim.y == 1) {
+        const uint32_t o = idx_s[i];
+        ax[o] += (T)(G * tx[k]); ay[o] += (T)(G * ty[k]); az[o] += (T)(G * tz[k]);
+      } else {
+        double* p = part + (size_t)blockIdx.y * 3 * (size_t)n;
+        p[i] = tx[k]; p[(size_t)n + i] = ty[k]; p[2 * (size_t)n + i] = tz[k];
+      }
     }
   }
+}
+
+// a[idx_s[i]] += G * sum_{y<ny} part[y][c][i]   (fixed order: bit-reproducible)
+template <typename T>
+__global__ void __launch_bounds__(256)
+sr_reduce_kernel(const double* __restrict__ part, int ny, const uint32_t* __restrict__ idx_s, int64_t n, double G, T* __restrict__ ax,
+                 T* __restrict__ ay, T* __restrict__ az) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  for (int y = 0; y < ny; ++y) {
+    const double* p = part + (size_t)y * 3 * (size_t)n;
+    sx += p[i]; sy += p[(size_t)n + i]; sz += p[2 * (size_t)n + i];
+  }
+  const uint32_t o = idx_s[i];
+  ax[o] += (T)(G * sx); ay[o] += (T)(G * sy); az[o] += (T)(G * sz);
 }
 
 inline int stream_grid(int64_t n) {
@@ -591,11 +623,33 @@ int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z,
     NB_HIP(c, hipGetLastError());
     s.table_alpha = alpha; s.table_rcut = rcut;
   }
-#define NB_SR(K) short_range_kernel<T, V4, K><<<(unsigned)((max_chunks + SRW - 1) / SRW), 64 * SRW, 0, st>>>((const V4*)s.sorted, s.keys_s, \
-    s.cell_start, s.chunk_off, nrows, nc, (T)L, (T)alpha, (T)(rcut * rcut), (T)eps2, G, s.idx_s, s.table, ax, ay, az)
+  // fewer chunks than ~4 waves per SIMD: one wave per (chunk, neighbouring row, z-part) — 9 x zparts the waves, each that fraction of the
+  // serial walk (the 32^3 farm jobs of the thesis: 256 chunks; short-range kernel 1.41 ms -> see DESIGN.md §6.7); partial sums go
+  // through an fp64 slab and are added in a fixed order
+  static const int zp_env = getenv("NB_SR_ZPARTS") ? atoi(getenv("NB_SR_ZPARTS")) : 0;
+  int ny = 1;
+  if (max_chunks < 4096) {
+    int zparts = zp_env > 0 ? zp_env : (max_chunks < 1024 ? 3 : (max_chunks < 2048 ? 2 : 1));
+    if (zparts > 4) zparts = 4;
+    ny = 9 * zparts;
+  }
+  double* part = nullptr;
+  if (ny > 1) {
+    rc = nb_ensure_work(c, (size_t)ny * 3 * (size_t)n * sizeof(double));
+    if (rc) return rc;
+    part = reinterpret_cast<double*>(c->work);
+    NB_HIP(c, hipMemsetAsync(part, 0, (size_t)ny * 3 * (size_t)n * sizeof(double), st));   // waves without work write nothing
+  }
+  const dim3 sr_grid((unsigned)((max_chunks + SRW - 1) / SRW), (unsigned)ny);
+#define NB_SR(K) short_range_kernel<T, V4, K><<<sr_grid, 64 * SRW, 0, st>>>((const V4*)s.sorted, s.keys_s, \
+    s.cell_start, s.chunk_off, nrows, nc, (T)L, (T)alpha, (T)(rcut * rcut), (T)eps2, G, s.idx_s, s.table, ax, ay, az, part, n)
   if (ks == 1) NB_SR(1); else if (ks == 2) NB_SR(2); else NB_SR(4);
 #undef NB_SR
   NB_HIP(c, hipGetLastError());
+  if (ny > 1) {
+    sr_reduce_kernel<T><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(part, ny, s.idx_s, n, G, ax, ay, az);
+    NB_HIP(c, hipGetLastError());
+  }
   return NB_OK;
 }
 

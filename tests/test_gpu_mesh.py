@@ -239,8 +239,12 @@ def test_graph_replayed_run_equals_eager_steps(solver, dtype):
                 for a, b, c in zip(k1[:3], d[:3], k2[:3]):
                     e.kdk_step(a, b, c, 0.1)
             out.append(e.get_state())
-    np.testing.assert_array_equal(out[0].pos, out[1].pos)
-    np.testing.assert_array_equal(out[0].vel, out[1].vel)
+    if solver == "pm":          # small-n PM deposits with fp64 global atomics: the summation order differs from run to run (last bits)
+        np.testing.assert_allclose(out[0].pos, out[1].pos, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(out[0].vel, out[1].vel, rtol=0, atol=1e-10)
+    else:
+        np.testing.assert_array_equal(out[0].pos, out[1].pos)
+        np.testing.assert_array_equal(out[0].vel, out[1].vel)
 
 
 def test_contexts_release_all_device_memory():
