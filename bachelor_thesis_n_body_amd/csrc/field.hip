@@ -138,13 +138,14 @@ r2c_kernel(const double* __restrict__ g, hipfftDoubleComplex* __restrict__ c, si
 }
 
 __global__ void __launch_bounds__(256)
-window_kernel(hipfftDoubleComplex* __restrict__ c, const double* __restrict__ w1d, int N) {
+window_kernel(hipfftDoubleComplex* __restrict__ c, const double* __restrict__ w1d, int N, double clip) {
   const size_t n = (size_t)N * N * N;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(idx % N), j = (int)((idx / N) % N), i = (int)(idx / ((size_t)N * N));
     const double t = (w1d[i] * w1d[j]) * w1d[k];
     double W = t * t;
-    if (W == 0.0) W = 1.0;
+    if (clip > 0.0) W = W < clip ? clip : W;           // np.clip(W, clip, None): 1LPTvs2LPT/1vs2tlptplotter.py:89-91, Different_Sizes/Plotter.py:159-164
+    else if (W == 0.0) W = 1.0;
     c[idx].x = c[idx].x / W;
     c[idx].y = c[idx].y / W;
   }
@@ -376,11 +377,28 @@ int nbf_grid_affine(nbf_plan* p, double div1, double div2, double sub) {
   return NB_OK;
 }
 
-int nbf_deconvolve(nbf_plan* p) {
+// the grid rounded to float32 and back: the plotting scripts that deposit into a float32 array (Different_Sizes/Plotter.py:167)
+__global__ void __launch_bounds__(256)
+round_f32_kernel(double* __restrict__ g, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) g[i] = (double)(float)g[i];
+}
+
+int nbf_grid_round_f32(nbf_plan* p) {
   if (!p) return NB_ERR_ARG;
   int rc = use_dev(p); if (rc) return rc;
+  round_f32_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->grid, p->cells);
+  F_HIP(p, hipGetLastError());
+  return NB_OK;
+}
+
+int nbf_deconvolve(nbf_plan* p) { return nbf_deconvolve_clip(p, 0.0); }
+
+int nbf_deconvolve_clip(nbf_plan* p, double clip) {
+  if (!p) return NB_ERR_ARG;
+  if (!(clip >= 0.0)) return ffail(p, NB_ERR_ARG, "nbf_deconvolve_clip: clip must be >= 0");
+  int rc = use_dev(p); if (rc) return rc;
   rc = forward_fft(p); if (rc) return rc;
-  window_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->cgrid, p->w1d, p->ngrid);
+  window_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->cgrid, p->w1d, p->ngrid, clip);
   F_HIP(p, hipGetLastError());
   F_FFT(p, hipfftExecZ2Z(p->fft, p->cgrid, p->cgrid, HIPFFT_BACKWARD));
   c2r_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->cgrid, p->grid, p->cells, 1.0 / (double)p->cells);

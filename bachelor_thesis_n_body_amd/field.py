@@ -31,6 +31,8 @@ FIELD_SIGNATURES = {
     "nbf_grid_mean": (_int, [_vp, C.POINTER(_dbl)]),
     "nbf_grid_affine": (_int, [_vp, _dbl, _dbl, _dbl]),
     "nbf_deconvolve": (_int, [_vp]),
+    "nbf_deconvolve_clip": (_int, [_vp, _dbl]),
+    "nbf_grid_round_f32": (_int, [_vp]),
     "nbf_get_grid": (_int, [_vp, _vp]),
     "nbf_set_grid": (_int, [_vp, _vp]),
     "nbf_power_bins": (_int, [_vp, _dbl, _vp, _vp]),
@@ -120,8 +122,12 @@ class FieldPlan:
     def affine(self, div1: float, div2: float, sub: float) -> None:
         self._chk(self._lib.nbf_grid_affine(self._p, div1, div2, sub), "nbf_grid_affine")
 
-    def deconvolve(self) -> None:
-        self._chk(self._lib.nbf_deconvolve(self._p), "nbf_deconvolve")
+    def deconvolve(self, clip: float = 0.0) -> None:
+        self._chk(self._lib.nbf_deconvolve_clip(self._p, float(clip)), "nbf_deconvolve_clip")
+
+    def round_f32(self) -> None:
+        """grid <- float32(grid): the density of the scripts that deposit into a float32 array (Different_Sizes/Plotter.py:167)."""
+        self._chk(self._lib.nbf_grid_round_f32(self._p), "nbf_grid_round_f32")
 
     def get(self) -> np.ndarray:
         out = np.empty((self.ngrid,) * 3, np.float64)
@@ -204,6 +210,28 @@ def power_spectrum(positions, L: float, Nmesh: int, deconvolve: bool = False, us
     pk = np.zeros_like(k_centers)
     pk[valid] = psum[valid] / counts[valid]
     return k_centers[valid], pk[valid], counts[valid]
+
+
+def power_spectrum_plotter(positions, boxsize: float, Nmesh: int, nbins: int = 100, grid_dtype=np.float64, clip: float = 1e-3,
+                           device: int = 0):
+    """(k_centers[valid], Pk_binned[valid]) — the estimator of the thesis' two plotting scripts after their h5py read:
+    1LPTvs2LPT/1vs2tlptplotter.py:81-116 (float64 grid, 100 bin edges) and Different_Sizes/Plotter.py:148-202 (float32 grid:
+    `grid_dtype=np.float32`, 300 edges): CIC deposit, delta = n / nbar - 1, fftn(delta) / clip(W_CIC, 1e-3), |.|^2 V / N^6, log-spaced
+    bins from k_min to the corner mode. The float32 variant rounds the deposited grid to float32 once (the script accumulates in
+    float32 particle by particle; the difference is ~1e-7 relative, below the estimator's own round-off)."""
+    pos = np.ascontiguousarray(positions, np.float64)
+    with FieldPlan(Nmesh, boxsize, device) as p:
+        p.cic(pos)
+        if np.dtype(grid_dtype) == np.float32:
+            p.round_f32()
+        p.affine(pos.shape[0] / Nmesh ** 3, 1.0, 1.0)          # delta / rho_mean - 1
+        if np.dtype(grid_dtype) == np.float32:
+            p.round_f32()
+        p.deconvolve(clip)
+        kbins, psum, counts = p.power_bins(boxsize ** 3 / Nmesh ** 6, nbins)
+    k_centers = 0.5 * (kbins[:-1] + kbins[1:])
+    valid = counts > 0
+    return k_centers[valid], psum[valid] / counts[valid]
 
 
 def compute_power_spectrum_from_snapshot(snapshot_path: str, L: float, Nmesh: int, deconvolve: bool = False,

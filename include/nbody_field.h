@@ -40,6 +40,11 @@ int nbf_grid_mean(nbf_plan* plan, double* mean);
 int nbf_grid_affine(nbf_plan* plan, double div1, double div2, double sub);
 /* grid <- real(ifftn(fftn(grid) / W)) */
 int nbf_deconvolve(nbf_plan* plan);
+/* the same with the window clipped from below, W = max(W, clip) — the estimator variant of 1LPTvs2LPT/1vs2tlptplotter.py:81-116 and
+ * Different_Sizes/Plotter.py:148-202 (`np.clip(W_CIC, 1e-3, None)`); clip = 0 is nbf_deconvolve */
+int nbf_deconvolve_clip(nbf_plan* plan, double clip);
+/* grid <- (double)(float)grid: the density of the scripts that deposit into a float32 array (Different_Sizes/Plotter.py:167) */
+int nbf_grid_round_f32(nbf_plan* plan);
 /* copy the real grid out / in (ngrid^3 doubles, C order [i][j][k]) */
 int nbf_get_grid(nbf_plan* plan, double* out);
 int nbf_set_grid(nbf_plan* plan, const double* in);

@@ -122,3 +122,29 @@ def power_spectrum(positions, L: float, Nmesh: int, deconvolve: bool = False, us
     Pk_binned = np.zeros_like(k_centers)
     Pk_binned[valid] = Psum[valid] / counts[valid]
     return k_centers[valid], Pk_binned[valid], counts[valid]
+
+
+def power_spectrum_plotter(positions, boxsize: float, Nmesh: int, nbins: int = 100, grid_dtype=np.float64, clip: float = 1e-3):
+    """Restatement of the estimator of the thesis' plotting scripts, line by line after the h5py read:
+    1LPTvs2LPT/1vs2tlptplotter.py:81-116 (`nbins=100`, float64 grid) and Different_Sizes/Plotter.py:148-202 (`nbins=300`,
+    `grid_dtype=np.float32`: the density is accumulated in a float32 array, Plotter.py:167)."""
+    coords = np.asarray(positions, np.float64)
+    k_vals = 2 * np.pi * np.fft.fftfreq(Nmesh, d=boxsize / Nmesh)
+    kx, ky, kz = np.meshgrid(k_vals, k_vals, k_vals, indexing="ij")
+    k_mag = np.sqrt(kx ** 2 + ky ** 2 + kz ** 2)
+    k_quist = np.pi * Nmesh / boxsize
+    W = np.clip((np.sinc(kx / (2 * k_quist)) * np.sinc(ky / (2 * k_quist)) * np.sinc(kz / (2 * k_quist))) ** 2, clip, None)
+    delta = cic_density(coords, boxsize, Nmesh).astype(grid_dtype)        # the scripts' cic_assign is the same deposit (weights 1)
+    rho_mean = coords.shape[0] / Nmesh ** 3
+    delta = delta / rho_mean - 1.0
+    delta_k = np.fft.fftn(delta) / W
+    Pk = np.abs(delta_k) ** 2 * boxsize ** 3 / (Nmesh ** 6)
+    k_min, k_max = 2 * np.pi / boxsize, k_mag.max()
+    bins = np.logspace(np.log10(k_min), np.log10(k_max), nbins)
+    centers = 0.5 * (bins[:-1] + bins[1:])
+    kf, Pf = k_mag.ravel(), Pk.ravel()
+    mask = kf > 0
+    counts, _ = np.histogram(kf[mask], bins=bins)
+    sums, _ = np.histogram(kf[mask], bins=bins, weights=Pf[mask])
+    nz = counts > 0
+    return centers[nz], sums[nz] / counts[nz]

@@ -152,3 +152,16 @@ def test_momentum_fixture_obeys_linear_continuity():
     pdel = np.loadtxt(G / "p3m_farm_test100_pk.txt")[:, 4]
     lin = (float(c.H(1.0)) * c.growth(1.0)[1]) ** 2
     assert pdiv[0] / pdel[0] == pytest.approx(lin, rel=0.03) and pdiv[1] / pdel[1] == pytest.approx(lin, rel=0.06)
+
+
+def test_plotter_estimator_restatement_against_the_power_compare_one():
+    """oracle.power_spectrum_plotter (1vs2tlptplotter.py:81-116 / Plotter.py:148-202) vs oracle.power_spectrum (Power_compare.py): same
+    deposit, same bins for nbins = 300; they differ only where the clipped window differs from the plain one (|k| next to the Nyquist planes:
+    W >= 1e-3 everywhere for CIC on this grid except the corner region)."""
+    pos = sn.read_positions(str(G / "test_id0200_snapshot_a=1.00.hdf5"))
+    k1, p1, _ = fo.power_spectrum(pos, 500.0, 32, deconvolve=True, nbins=300)
+    k2, p2 = fo.power_spectrum_plotter(pos, 500.0, 32, 300, np.float64, clip=1e-30)
+    np.testing.assert_allclose(k1, k2, rtol=1e-14)
+    np.testing.assert_allclose(p1, p2, rtol=1e-9)
+    k3, p3 = fo.power_spectrum_plotter(pos, 500.0, 32, 300, np.float32)          # float32 grid: 1e-7-level differences only
+    np.testing.assert_allclose(p3[: len(p3) // 2], p2[: len(p3) // 2], rtol=1e-4)

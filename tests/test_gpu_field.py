@@ -101,3 +101,22 @@ def test_plan_reuse_and_engine_state_roundtrip(tmp_path):
     np.testing.assert_allclose(b, fo.delta_field(pos, box, 32, True), rtol=1e-11, atol=1e-11)
     np.testing.assert_allclose(a, c, rtol=1e-11, atol=1e-11)   # atomics: order-dependent only at round-off (x FFT gain)
     assert abs(b.mean()) < 1e-14
+
+
+@pytest.mark.parametrize("nbins,grid_dtype,tol", [(100, np.float64, 1e-10), (300, np.float32, 2e-5)])
+def test_plotting_script_estimator_variants(nbins, grid_dtype, tol):
+    """The P(k) estimator of the thesis' two plotting scripts (1LPTvs2LPT/1vs2tlptplotter.py:81-116: float64 grid, 100 bin edges;
+    Different_Sizes/Plotter.py:148-202: float32 grid, 300 edges): window clipped at 1e-3, log bins up to the corner mode — on a reference
+    snapshot, GPU chain vs the line-by-line restatement."""
+    from bachelor_thesis_n_body_amd import snapshot as sn
+    pos = sn.read_positions(str(GOLD / "test_id0200_snapshot_a=1.00.hdf5"))
+    for nmesh in (32, 48):
+        k, p = field.power_spectrum_plotter(pos, 500.0, nmesh, nbins, grid_dtype)
+        k0, p0 = fo.power_spectrum_plotter(pos, 500.0, nmesh, nbins, grid_dtype)
+        np.testing.assert_allclose(k, k0, rtol=1e-14)
+        np.testing.assert_allclose(p, p0, rtol=tol)
+    # the clip only matters next to the Nyquist planes: away from them this is the deconvolved estimator of Power_compare.py
+    k1, p1, _ = field.power_spectrum(pos, 500.0, 32, deconvolve=True, nbins=100)
+    k2, p2 = field.power_spectrum_plotter(pos, 500.0, 32, 100, np.float64, clip=1e-30)
+    np.testing.assert_allclose(k1, k2, rtol=1e-14)
+    np.testing.assert_allclose(p1, p2, rtol=1e-9)
