@@ -108,8 +108,7 @@ def test_plotting_script_estimator_variants(nbins, grid_dtype, tol):
     """The P(k) estimator of the thesis' two plotting scripts (1LPTvs2LPT/1vs2tlptplotter.py:81-116: float64 grid, 100 bin edges;
     Different_Sizes/Plotter.py:148-202: float32 grid, 300 edges): window clipped at 1e-3, log bins up to the corner mode — on a reference
     snapshot, GPU chain vs the line-by-line restatement."""
-    from bachelor_thesis_n_body_amd import snapshot as sn
-    pos = sn.read_positions(str(GOLD / "test_id0200_snapshot_a=1.00.hdf5"))
+    pos = sn.read_positions(str(G / "test_id0200_snapshot_a=1.00.hdf5"))
     for nmesh in (32, 48):
         k, p = field.power_spectrum_plotter(pos, 500.0, nmesh, nbins, grid_dtype)
         k0, p0 = fo.power_spectrum_plotter(pos, 500.0, nmesh, nbins, grid_dtype)
