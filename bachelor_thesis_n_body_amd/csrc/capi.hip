@@ -491,9 +491,9 @@ int nb_step_energy(nb_ctx* c, double dt, int64_t nsteps, double eps, double G, d
   if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_step_energy: call nb_set_state first");
   if (nsteps < 0) return nb_fail(c, NB_ERR_ARG, "nb_step_energy: nsteps must be >= 0");
   if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_step_energy: eps must be >= 0");
-  NB_SINGLE_ONLY(c, "nb_step_energy");
   if (c->solver != NB_SOLVER_DIRECT) return nb_fail(c, NB_ERR_ARG, "nb_step_energy: direct solver only");
   if (nsteps == 0) return NB_OK;
+  if (c->multi) return nb_multi_step_energy(c, dt, nsteps, eps, G, kinetic, potential);
   int rc = use_device(c); if (rc) return rc;
   if (!c->phi) NB_HIP(c, hipMalloc(&c->phi, (size_t)c->n * sizeof(double)));
   if (c->elog_cap < nsteps) {

@@ -393,7 +393,9 @@ __device__ inline double sr_factor(double r2, double eps2, double alpha, double 
 // cut-off test, so every sink sees each of its 27 neighbour-cell images exactly once.
 constexpr int SRW = 4;      // waves (= independent chunks) per block; they share only the look-up table
 
-template <typename T, typename V4, int KS>
+// SOFT: eps > 0, so the softened term is finite for a coincident pair (the particle itself): no r = 0 guard in the loop (its dx = 0 kills the
+// term). UNI: all masses equal — the per-pair mass multiply is dropped and the common mass applied once with G at the end.
+template <typename T, typename V4, int KS, bool SOFT, bool UNI>
 __global__ void __launch_bounds__(64 * SRW)
 short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ keys_s, const int* __restrict__ cell_start,
                    const int* __restrict__ chunk_off, int nrows, int nc, T L, T alpha, T rcut2, T eps2, double G,
@@ -480,17 +482,17 @@ short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ k
               if (__builtin_amdgcn_ballot_w64(r2 < rcut2) != 0) {
                 T pair;
                 if constexpr (TABLE) {
-                  const float t = (float)r2 * tscale;
-                  const int it = min((int)t, TABN);                  // lanes beyond the cut-off are masked below
-                  const float fr = t - (float)it;
+                  const float t = fminf((float)r2 * tscale, (float)TABN);   // lanes beyond the cut-off are masked below
+                  const int it = (int)t;
+                  const float fr = __builtin_amdgcn_fractf(t);             // t - floor(t): one instruction, no int -> float round trip
                   const float t0 = tab[it], t1 = tab[it + 1];
                   const float sinv = __builtin_amdgcn_rsqf((float)r2 + (float)eps2);
-                  const float soft = r2 > (T)0 ? sinv * sinv * sinv : 0.f;
+                  const float soft = (SOFT || r2 > (T)0) ? sinv * sinv * sinv : 0.f;
                   pair = soft - fmaf(fr, t1 - t0, t0);
                 } else {
                   pair = sr_factor(r2, eps2, alpha, c2, a2l);
                 }
-                T f = s.w * pair;
+                T f = UNI ? pair : s.w * pair;
                 f = r2 < rcut2 ? f : (T)0;
                 fx[k] += f * dx; fy[k] += f * dy; fz[k] += f * dz;
               }
@@ -505,12 +507,14 @@ short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ k
   for (int k = 0; k < KS; ++k) {
     const int i = i_first + k * 64 + lane;
     if (i <= i_last) {
+      const double g = UNI ? G * (double)sorted[0].w : G;          // equal masses: the common mass comes in here
       if (gridDim.y == 1) {
         const uint32_t o = idx_s[i];
-        ax[o] += (T)(G * tx[k]); ay[o] += (T)(G * ty[k]); az[o] += (T)(G * tz[k]);
+        ax[o] += (T)(g * tx[k]); ay[o] += (T)(g * ty[k]); az[o] += (T)(g * tz[k]);
       } else {
         double* p = part + (size_t)blockIdx.y * 3 * (size_t)n;
-        p[i] = tx[k]; p[(size_t)n + i] = ty[k]; p[2 * (size_t)n + i] = tz[k];
+        const double m0 = UNI ? (double)sorted[0].w : 1.0;        // sr_reduce_kernel applies G
+        p[i] = m0 * tx[k]; p[(size_t)n + i] = m0 * ty[k]; p[2 * (size_t)n + i] = m0 * tz[k];
       }
     }
   }
@@ -641,10 +645,14 @@ int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z,
     NB_HIP(c, hipMemsetAsync(part, 0, (size_t)ny * 3 * (size_t)n * sizeof(double), st));   // waves without work write nothing
   }
   const dim3 sr_grid((unsigned)((max_chunks + SRW - 1) / SRW), (unsigned)ny);
-#define NB_SR(K) short_range_kernel<T, V4, K><<<sr_grid, 64 * SRW, 0, st>>>((const V4*)s.sorted, s.keys_s, \
+  const bool soft = eps2 > 0.0 && (sizeof(T) == 8 || (float)eps2 > 1e-30f), uni = c->uniform_mass;
+#define NB_SR2(K, SF, UN) short_range_kernel<T, V4, K, SF, UN><<<sr_grid, 64 * SRW, 0, st>>>((const V4*)s.sorted, s.keys_s, \
     s.cell_start, s.chunk_off, nrows, nc, (T)L, (T)alpha, (T)(rcut * rcut), (T)eps2, G, s.idx_s, s.table, ax, ay, az, part, n)
+#define NB_SR(K) do { if (soft && uni) NB_SR2(K, true, true); else if (soft) NB_SR2(K, true, false); else if (uni) NB_SR2(K, false, true); \
+                      else NB_SR2(K, false, false); } while (0)
   if (ks == 1) NB_SR(1); else if (ks == 2) NB_SR(2); else NB_SR(4);
 #undef NB_SR
+#undef NB_SR2
   NB_HIP(c, hipGetLastError());
   if (ny > 1) {
     sr_reduce_kernel<T><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(part, ny, s.idx_s, n, G, ax, ay, az);

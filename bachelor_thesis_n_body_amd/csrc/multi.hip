@@ -93,20 +93,22 @@ int wait_for_readers(nb_ctx* c, int o) {
   return NB_OK;
 }
 
-int refresh_acc(nb_ctx* c, double eps, double G) {
+// with_phi: the fused force+potential kernels accumulate shard->phi over the chunks as well (nb_step_energy)
+int refresh_acc(nb_ctx* c, double eps, double G, bool with_phi = false) {
   nb_multi_state& m = *c->multi;
   const size_t es = esz(c->dtype);
   int rc = for_each_chunk(c, [&](int g, int o, const char* src, bool first) -> int {
     nb_ctx* s = m.shard[g];
     const size_t so = (size_t)m.cnt[o] * es;
     const int flags = (first ? 0 : NB_ACCUMULATE) | (m.uniform ? NB_UNIFORM_MASS : 0);
+    double* phi = with_phi ? s->phi : nullptr;
     if (c->dtype == NB_F32)
       return nb_launch_accel_f32(s, (const float*)field_ptr(s, 0), (const float*)field_ptr(s, 1), (const float*)field_ptr(s, 2), s->n,
                                  (const float*)src, (const float*)(src + so), (const float*)(src + 2 * so), (const float*)(src + 3 * so), m.cnt[o],
-                                 (float)(eps * eps), (float)G, (float*)field_ptr(s, 7), (float*)field_ptr(s, 8), (float*)field_ptr(s, 9), flags);
+                                 (float)(eps * eps), (float)G, (float*)field_ptr(s, 7), (float*)field_ptr(s, 8), (float*)field_ptr(s, 9), flags, phi);
     return nb_launch_accel_f64(s, (const double*)field_ptr(s, 0), (const double*)field_ptr(s, 1), (const double*)field_ptr(s, 2), s->n,
                                (const double*)src, (const double*)(src + so), (const double*)(src + 2 * so), (const double*)(src + 3 * so), m.cnt[o],
-                               eps * eps, G, (double*)field_ptr(s, 7), (double*)field_ptr(s, 8), (double*)field_ptr(s, 9), flags);
+                               eps * eps, G, (double*)field_ptr(s, 7), (double*)field_ptr(s, 8), (double*)field_ptr(s, 9), flags, phi);
   });
   if (rc) return rc;
   m.acc_valid = true; m.acc_eps = eps; m.acc_G = G;
@@ -296,6 +298,58 @@ int nb_multi_energy(nb_ctx* c, double eps, double G, double* kinetic, double* po
   rc = sync_all(c); if (rc) return rc;
   if (kinetic) *kinetic = K;
   if (potential) *potential = -0.5 * G * W;
+  return NB_OK;
+}
+
+// KDK steps with the energies of the WHOLE system after every step: each device keeps a log of (K, W) partials of its own sinks — the potential
+// from the fused force+potential kernels, accumulated over the chunks as they arrive — and the host adds the P logs once, at the end.
+int nb_multi_step_energy(nb_ctx* c, double dt, int64_t nsteps, double eps, double G, double* kinetic, double* potential) {
+  nb_multi_state& m = *c->multi;
+  int rc;
+  for (int g = 0; g < m.P; ++g) {
+    MHIP(c, hipSetDevice(m.dev[g]));
+    nb_ctx* s = m.shard[g];
+    if (!s->phi) MHIP(c, hipMalloc((void**)&s->phi, (size_t)s->n * sizeof(double)));
+    if (s->elog_cap < nsteps) {
+      MHIP(c, hipStreamSynchronize(s->stream));
+      if (s->elog) { (void)hipFree(s->elog); s->elog = nullptr; s->elog_cap = 0; }
+      MHIP(c, hipMalloc((void**)&s->elog, (size_t)nsteps * 2 * sizeof(double)));
+      s->elog_cap = nsteps;
+    }
+  }
+  if (!nb_multi_acc_valid(c, eps, G)) { rc = refresh_acc(c, eps, G); if (rc) return rc; }
+  const double h = 0.5 * dt;
+  for (int64_t k = 0; k < nsteps; ++k) {
+    for (int g = 0; g < m.P; ++g) {
+      MHIP(c, hipSetDevice(m.dev[g]));
+      nb_ctx* s = m.shard[g];
+      rc = wait_for_readers(c, g); if (rc) return rc;
+      rc = nb_launch_kick_drift(s, c->dtype, field_ptr(s, 0), field_ptr(s, 1), field_ptr(s, 2), field_ptr(s, 4), field_ptr(s, 5), field_ptr(s, 6),
+                                field_ptr(s, 7), field_ptr(s, 8), field_ptr(s, 9), s->n, 0.0, h, dt);
+      if (rc) return nb_fail(c, rc, s->err);
+    }
+    rc = refresh_acc(c, eps, G, true); if (rc) return rc;
+    for (int g = 0; g < m.P; ++g) {
+      MHIP(c, hipSetDevice(m.dev[g]));
+      nb_ctx* s = m.shard[g];
+      rc = nb_launch_kick(s, c->dtype, field_ptr(s, 4), field_ptr(s, 5), field_ptr(s, 6), field_ptr(s, 7), field_ptr(s, 8), field_ptr(s, 9), s->n, h);
+      if (!rc) rc = nb_launch_kinetic(s, c->dtype, field_ptr(s, 4), field_ptr(s, 5), field_ptr(s, 6), field_ptr(s, 3), s->n, s->elog + 2 * k);
+      if (!rc) rc = nb_launch_pot_energy(s, c->dtype, s->phi, field_ptr(s, 3), s->n, eps * eps, c->dtype == NB_F32 && m.uniform, s->elog + 2 * k + 1);
+      if (rc) return nb_fail(c, rc, s->err);
+    }
+  }
+  std::vector<double> sum((size_t)nsteps * 2, 0.0), part((size_t)nsteps * 2);
+  for (int g = 0; g < m.P; ++g) {                              // fixed order: device 0, 1, ...
+    MHIP(c, hipSetDevice(m.dev[g]));
+    MHIP(c, hipMemcpyAsync(part.data(), m.shard[g]->elog, part.size() * sizeof(double), hipMemcpyDeviceToHost, m.shard[g]->stream));
+    MHIP(c, hipStreamSynchronize(m.shard[g]->stream));
+    for (size_t i = 0; i < sum.size(); ++i) sum[i] += part[i];
+  }
+  rc = sync_all(c); if (rc) return rc;
+  for (int64_t k = 0; k < nsteps; ++k) {
+    if (kinetic) kinetic[k] = sum[2 * k];
+    if (potential) potential[k] = -0.5 * G * sum[2 * k + 1];
+  }
   return NB_OK;
 }
 

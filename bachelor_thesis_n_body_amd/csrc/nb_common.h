@@ -90,6 +90,7 @@ bool nb_multi_acc_valid(const nb_ctx* c, double eps, double G);
 bool nb_multi_has_acc(const nb_ctx* c);
 int nb_multi_kdk(nb_ctx* c, int64_t nsteps, const double* kick1, const double* drift, const double* kick2, double eps, double G);
 int nb_multi_energy(nb_ctx* c, double eps, double G, double* kinetic, double* potential);
+int nb_multi_step_energy(nb_ctx* c, double dt, int64_t nsteps, double eps, double G, double* kinetic, double* potential);
 int nb_multi_sync(nb_ctx* c);
 int nb_multi_info(const nb_ctx* c, int which, int64_t* out, int cap);
 int nb_bh_check(nb_ctx* c);   // call after a stream sync

@@ -151,6 +151,51 @@ def self_launch(args) -> int:
     return rc
 
 
+def single_process(args) -> int:
+    """The same workload through nb_create_multi (include/nbody_amd.h): one process, N devices, every device pulls the other owners'
+    source blocks peer to peer while its force kernel works on the block before. No torch in this path."""
+    import bachelor_thesis_n_body_amd as nb
+    from bachelor_thesis_n_body_amd import _lib
+    ndev = _lib.load().nb_device_count()
+    if ndev <= 0:
+        print("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)", file=sys.stderr)
+        return 1
+    devices = [0] * args.gpus if args.same_device else list(range(args.gpus))
+    if max(devices) >= ndev:
+        print(f"--gpus {args.gpus}: only {ndev} device(s) visible; use --same-device to rehearse on one GPU", file=sys.stderr)
+        return 1
+    np_dtype = np.float32 if args.dtype == "f32" else np.float64
+    eps, dt, G = 0.01, 1.0 / 256.0, 1.0
+    state = nb.plummer_sphere(args.n, seed=0, dtype=np_dtype)
+    if args.general_mass:
+        state.mass[-1] = np.nextafter(state.mass[-1], np_dtype(1.0))
+    with nb.Engine(args.n, np_dtype, devices=devices) as eng:
+        eng.set_state(state)
+        eng.accel(eps, G, fetch=False)
+        for _ in range(args.warmup):
+            eng.step(dt, 1, eps, G)
+        t0 = time.perf_counter()
+        eng.step(dt, args.steps, eps, G)          # ONE call: no host synchronisation between the steps; returns synchronised
+        elapsed = time.perf_counter() - t0
+    value = float(args.n) * float(args.n) * args.steps / elapsed
+    peak = PEAK_FP32_VECTOR_TFLOPS if args.dtype == "f32" else PEAK_FP64_VECTOR_TFLOPS
+    achieved = value * FLOP_PER_INTERACTION / 1e12 / len(devices)
+    out = {"metric": "particle-pair interactions/s", "value": value, "unit": "interactions/s", "n_gpus": args.gpus, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"plummer_sphere N={args.n} {args.dtype} eps=0.01 dt=1/256, KDK step = 1 all-pairs force evaluation", "n": args.n,
+                      "parallelism": f"nb_create_multi: one process, sink-decomposition x{args.gpus}, peer pulls of source blocks",
+                      "masses": "general (one mass perturbed by 1 ulp)" if args.general_mass else "equal"},
+           "world_size": args.gpus, "backend": "hipMemcpyPeerAsync (single process)", "same_device": bool(args.same_device), "ring": None,
+           "roofline": {"bound": "vector_" + ("fp32" if args.dtype == "f32" else "fp64"), "kernel": "accel_%s_kernel" % args.dtype,
+                        "variant": "general" if args.general_mass else "uniform_mass", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                        "frac": achieved / peak, "flop_per_interaction": FLOP_PER_INTERACTION,
+                        "note": "per device, from the whole step (exchange and O(N) kernels included); kernel events are not visible from outside the library",
+                        "traffic": None}}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,13 +207,18 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (default); gloo for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="all ranks share cuda:0 (one-GPU rehearsal; needs --backend gloo)")
     ap.add_argument("--general-mass", action="store_true", help="perturb one mass by 1 ulp: times the per-source-mass kernel")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive the N GPUs from THIS process through the C-ABI's multi-device context (nb_create_multi: peer pulls of the "
+                         "source blocks, no torch.distributed); with --same-device all N shards sit on GPU 0 (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.same_device and args.backend == "nccl" and args.gpus > 1:
+    if args.same_device and args.backend == "nccl" and args.gpus > 1 and not args.single_process:
         raise SystemExit("--same-device needs --backend gloo (RCCL refuses two ranks on one device)")
 
+    if args.single_process:
+        raise SystemExit(single_process(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
 

@@ -67,9 +67,9 @@ int nb_create(nb_ctx** out, int64_t n, int dtype, int device);
  * sinks (the first n % ndev devices one particle more) and integrates only those; at every force evaluation each device pulls the
  * (x,y,z,m) block of every other owner over xGMI (peer copies on a copy stream, overlapped with the kernel on the block before), sums
  * chunk by chunk, no reduction of accelerations. One host thread drives all devices; nothing synchronises inside nb_step. Supported on
- * such a context: nb_set_state / nb_get_state / nb_accel / nb_get_acc / nb_step / nb_kdk_step / nb_kdk_run / nb_energy /
- * nb_synchronize / nb_destroy with GLOBAL host arrays of n elements — results equal the single-device context's up to the summation
- * order of the chunks. Everything else (tree / periodic / mesh solvers, nb_set_stream, nb_step_energy, the _dev surface) returns
+ * such a context: nb_set_state / nb_get_state / nb_accel / nb_get_acc / nb_step / nb_step_energy / nb_kdk_step / nb_kdk_run /
+ * nb_energy / nb_synchronize / nb_destroy with GLOBAL host arrays of n elements — results equal the single-device context's up to the summation
+ * order of the chunks. Everything else (tree / periodic / mesh solvers, nb_set_stream, the _dev surface) returns
  * NB_ERR_ARG. A device may be listed more than once (rehearsal of the P-device schedule on one GPU). */
 int nb_create_multi(nb_ctx** out, int64_t n, int dtype, int ndev, const int* dev_ids);
 /* sink ranges of a context: fills counts[g], offsets[g] for g < min(cap, ndev) (either may be NULL), returns ndev (1 for nb_create) */

@@ -89,14 +89,18 @@ def mesh_accel(pos, mass, L, ngrid, G=1.0, rs=None, interlace=True):
     return acc
 
 
-def short_range_accel(pos, mass, L, rs, rcut, eps=0.0, G=1.0, chunk=512):
+def short_range_accel(pos, mass, L, rs, rcut, eps=0.0, G=1.0, chunk=512, sinks=None):
+    """Erfc-complement pair force inside rcut, minimum image, all pairs (O(N^2)). `sinks`: indices of the particles whose acceleration is wanted
+    (default all) — lets a large configuration be checked on a sample."""
     pos = np.asarray(pos, np.float64); mass = np.asarray(mass, np.float64)
     pos = pos - L * np.floor(pos / L)
     n = pos.shape[0]
     alpha = 0.5 / rs
-    acc = np.zeros((n, 3))
-    for s in range(0, n, chunk):
-        d = pos[None, :, :] - pos[s:s + chunk, None, :]
+    snk = np.arange(n) if sinks is None else np.asarray(sinks)
+    chunk = max(1, min(chunk, int(2e7 // n)))
+    acc = np.zeros((len(snk), 3))
+    for s in range(0, len(snk), chunk):
+        d = pos[None, :, :] - pos[snk[s:s + chunk], None, :]
         d -= L * np.rint(d / L)
         r2 = (d * d).sum(-1)
         with np.errstate(divide="ignore", invalid="ignore"):

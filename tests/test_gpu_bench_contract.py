@@ -62,3 +62,13 @@ def test_bench_propagates_a_failing_rank():
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--n", "4096"],
                          capture_output=True, text=True, timeout=600)      # RCCL on a one-GPU box: rank 1 has no device
     assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_bench_single_process_multi_device_context():
+    """`--single-process`: the N-GPU workload through nb_create_multi (one process, peer pulls), rehearsed with both shards on GPU 0."""
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--single-process", "--same-device", "--steps", "3", "--warmup", "1",
+                          "--n", "65536"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert j["n_gpus"] == 2 and "nb_create_multi" in j["config"]["parallelism"] and j["value"] == pytest.approx(65536 ** 2 * 3 / (j["ms_per_step"] * 3e-3), rel=1e-6)
+    assert 0.05 < j["roofline"]["frac"] * 2 < 1.0          # two shards share one GPU here

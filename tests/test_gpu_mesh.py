@@ -61,6 +61,27 @@ def test_p3m_parts_match_oracle(dtype, clustered):
     assert np.abs(got - (ref_l + ref_s)).max() < tol * _scale(ref_s)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("eps", [0.2, 0.0])
+@pytest.mark.parametrize("n", [4000, 300000])
+def test_short_range_variants_equal_masses_and_zero_softening(dtype, eps, n):
+    """The four instantiations of the pair kernel: equal masses (mass multiply hoisted out of the loop) x eps > 0 (no r = 0 guard in the loop),
+    on few chunks (one wave per chunk, neighbouring row and z-part, fixed-order slab reduction) and on many (one wave per chunk) — against
+    the NumPy oracle on sampled sinks."""
+    if n > 4000 and eps == 0.0:
+        pytest.skip("covered at n = 4000")
+    L, ngrid = 80.0, 32 if n == 4000 else 96
+    pos, _ = _cloud(n, L, 5)
+    m = np.full(n, 0.75)
+    p = pos.astype(dtype).astype(np.float64)
+    rs = 1.25 * L / ngrid
+    got = _accel(pos, m, dtype, L, "p3m", ngrid, eps, part="short")
+    idx = np.arange(n) if n == 4000 else np.random.default_rng(1).choice(n, 256, replace=False)
+    ref = mo.short_range_accel(p, m, L, rs, 4.5 * rs, eps, sinks=idx) if n > 4000 else mo.short_range_accel(p, m, L, rs, 4.5 * rs, eps)
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    assert np.abs(got[idx] - ref).max() < tol * _scale(ref)
+
+
 def test_p3m_agrees_with_ewald_solver():
     """The two periodic solvers of the library against each other and against the Ewald oracle."""
     L, n, eps = 100.0, 3200, 0.3

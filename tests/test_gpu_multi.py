@@ -71,6 +71,26 @@ def test_multi_context_many_steps_with_buffer_reuse_fp64_is_deterministic_and_tr
     assert np.abs(runs[0].pos - o.pos).max() < 1e-11 and np.abs(runs[0].vel - o.vel).max() < 1e-10
 
 
+@pytest.mark.parametrize("dtype,uniform", [(np.float32, True), (np.float64, False)])
+def test_multi_context_step_with_energy(dtype, uniform):
+    """nb_step_energy on P devices: per-device (K, W) logs from the fused force+potential kernels, phi accumulated over the chunks, added on
+    the host — equal to the single-device log and to the separate energy pass at the final state."""
+    n = 5003
+    s = nb.plummer_sphere(n, 21, dtype)
+    if not uniform:
+        _general(s, dtype, 3)
+    with nb.Engine(n, dtype) as e:
+        e.set_state(s)
+        K1, U1 = e.step_with_energy(1 / 256, 4, 0.01)
+    with nb.Engine(n, dtype, devices=[0, 0, 0]) as e:
+        e.set_state(s)
+        K3, U3 = e.step_with_energy(1 / 256, 4, 0.01)
+        k, u = e.energy(0.01)
+    np.testing.assert_allclose(K3, K1, rtol=1e-5 if dtype == np.float32 else 1e-11)
+    np.testing.assert_allclose(U3, U1, rtol=3e-6 if dtype == np.float32 else 1e-11)
+    assert K3[-1] == pytest.approx(k, rel=1e-12) and U3[-1] == pytest.approx(u, rel=3e-6 if dtype == np.float32 else 1e-11)
+
+
 def test_multi_context_generalised_kdk_and_state_replacement():
     n = 3000
     s1 = nb.plummer_sphere(n, 3, np.float32)
@@ -102,7 +122,7 @@ def test_multi_context_rejects_what_it_does_not_support_and_bad_arguments():
         with pytest.raises(RuntimeError, match="multi-device"):
             e.set_periodic(10.0)
         with pytest.raises(RuntimeError, match="multi-device"):
-            e.step_with_energy(0.01, 1, 0.01)
+            e.set_stream(0)
         with pytest.raises(RuntimeError, match="no cached acceleration"):
             e.cached_acc()                                   # state, but no force evaluation yet
     with nb.Engine(64, np.float32) as e:                     # a plain context reports one device
