@@ -237,7 +237,12 @@ def run_pp(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: flo
         edges = np.exp(np.linspace(np.log(a_begin), np.log(a_end), nsteps + 1))
         mids = np.sqrt(edges[:-1] * edges[1:])
     else:
-        dts = load_concept_schedule()[2] if isinstance(schedule, str) and schedule == "concept" else np.asarray(schedule, np.float64)
+        if isinstance(schedule, str) and schedule == "concept":
+            a_fix, _, dts = load_concept_schedule()
+            # a run (or a leg of one, after an output time) that starts inside CONCEPT's k-th base step continues with that step's size
+            dts = dts[max(0, int(np.searchsorted(a_fix, a_begin * (1.0 + 1e-4), side="right")) - 1):]
+        else:
+            dts = np.asarray(schedule, np.float64)
         t_edges = concept_time_edges(cosmo, a_begin, a_end, dts)
         edges = np.array([cosmo.scale_factor(t) for t in t_edges])
         edges[0], edges[-1] = a_begin, a_end

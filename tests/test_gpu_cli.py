@@ -131,3 +131,26 @@ def test_cli_cosmological_run_resumes_from_its_own_snapshot(tmp_path):
     np.testing.assert_array_equal(sn.read_positions(str(resumed[0])), sn.read_positions(str(whole["snapshot_a=1.00.hdf5"])))
     np.testing.assert_array_equal(sn.read_momenta(str(resumed[0])), sn.read_momenta(str(whole["snapshot_a=1.00.hdf5"])))
     assert sn.read_attrs(str(resumed[0]))["Ωcdm"] > 0.2
+
+
+def test_cli_concept_schedule_with_an_intermediate_output(tmp_path):
+    """`--schedule concept`: CONCEPT's own base steps (fixture from the reference's logs). A run with an output at a = 0.5 (the leg
+    a = 0.02 -> 0.5 cut at the output time, the next leg continuing with the size of the base step it starts in) ends where the
+    one-leg run ends, up to the cut step; and it differs from the uniform-ln-a run only at the time-stepping level."""
+    k = np.logspace(-3, 1, 200)
+    np.savetxt(tmp_path / "pk.txt", np.column_stack([k, 2.0e4 * (k / 0.02) / (1 + (k / 0.02) ** 2) ** 1.6]))
+    out = {}
+    for name, extra in (("one", ["--schedule", "concept"]),
+                        ("two", ["--schedule", "concept", "-c", "output_times = {'snapshot': [0.5, 1.0]}"]),
+                        ("lna", ["--steps", "300"])):
+        d = tmp_path / name
+        d.mkdir()
+        f = _write(d, gravity="pm")
+        assert concept.main(["-p", str(f), "--cosmological", "--pk-table", str(tmp_path / "pk.txt")] + extra) == 0
+        out[name] = sn.read_positions(str(sorted(d.rglob("snapshot_a=1.00.hdf5"))[0]))
+    wrap = lambda x: np.abs((x + 250.0) % 500.0 - 250.0)
+    g = np.linspace(0, 500.0, 8, endpoint=False)
+    q = np.array(np.meshgrid(g, g, g, indexing="ij")).reshape(3, -1).T
+    moved = wrap(out["one"] - q).mean()                                  # mean displacement from the lattice at a = 1
+    assert wrap(out["one"] - out["two"]).max() < 2e-2 * moved            # one extra step boundary at a = 0.5
+    assert wrap(out["one"] - out["lna"]).mean() < 2e-2 * moved           # 143 CONCEPT steps vs 300 uniform ones: same trajectory
