@@ -359,7 +359,7 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
         const float4 q = mono[e];                                                    // LDS broadcast (ds_read_b128)
         const float qm = q.w;
         const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
-        const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) + eps2;
+        const float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));
         float rinv = __builtin_amdgcn_rsqf(r2);
         if (GUARD) rinv = r2 > 0.f ? rinv : 0.f;
         const float f = qm * rinv * rinv * rinv;
@@ -380,7 +380,7 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
           const float4 q = tile[e];
           const float qm = q.w;
           const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
-          const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) + eps2;
+          const float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));
           float rinv = __builtin_amdgcn_rsqf(r2);
           if (GUARD) rinv = r2 > 0.f ? rinv : 0.f;
           const float f = qm * rinv * rinv * rinv;

@@ -246,7 +246,7 @@ int bho_accel_list_f32(int n, const float* x, const float* y, const float* z, co
         for (int e = 0; e < nm; ++e) {
           const int v = mono[e];
           const float dx = t.cx[v] - t.sx[i], dy = t.cy[v] - t.sy[i], dz = t.cz[v] - t.sz[i];
-          const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) + eps2;
+          const float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));
           const float rinv = r2 > 0.f ? 1.0f / sqrtf(r2) : 0.f;
           const float f = t.cm[v] * rinv * rinv * rinv;
           a0 = fmaf(f, dx, a0); a1 = fmaf(f, dy, a1); a2 = fmaf(f, dz, a2);
@@ -255,7 +255,7 @@ int bho_accel_list_f32(int n, const float* x, const float* y, const float* z, co
           const int v = leaf[e];
           for (int j = t.first[v]; j < t.first[v] + t.count[v]; ++j) {
             const float dx = t.sx[j] - t.sx[i], dy = t.sy[j] - t.sy[i], dz = t.sz[j] - t.sz[i];
-            const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz)) + eps2;
+            const float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));
             const float rinv = r2 > 0.f ? 1.0f / sqrtf(r2) : 0.f;
             const float f = t.sm[j] * rinv * rinv * rinv;
             a0 = fmaf(f, dx, a0); a1 = fmaf(f, dy, a1); a2 = fmaf(f, dz, a2);
