@@ -30,7 +30,9 @@
 
 namespace {
 
-constexpr int NLEAF = 16;          // a rejected node with at most this many particles is summed directly
+constexpr int NLEAF = 16;          // ballot walk: a rejected node with at most this many particles is summed directly
+constexpr int NLEAF_LIST = 4;      // list walk: with the 8-box acceptance test a node test is cheap, opening small nodes beats summing them
+                                   // (N = 16M sweep, profiles/r02_bh_nleaf_sweep.txt: 2: 42.5 ms, 4: 41.2, 8: 42.3, 16: 46.0, 24: 50.2)
 constexpr int STACK = 192;         // per-wave stack entries (binary tree depth <= 63 key bits + 32 index bits)
 
 struct BHBuf {
@@ -271,7 +273,8 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
                  int* __restrict__ flags, int nleaf) {
   __shared__ float4 mono_all[4][64];
   __shared__ float4 tile_all[4][64];
-  __shared__ float4 gpos_all[4][64];
+  __shared__ float4 vlo_all[4][64];
+  __shared__ float4 vhi_all[4][64];
   __shared__ int lf_first_all[4][64];
   __shared__ int lf_pref_all[4][65];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -280,7 +283,8 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
   // accesses would serialise the sweeps below into dependent dword reads (measured 15x slower).
   float4* mono = mono_all[wave];
   float4* tile = tile_all[wave];
-  float4* gpos = gpos_all[wave];
+  float4* vlo = vlo_all[wave];
+  float4* vhi = vhi_all[wave];
   int* lf_first = lf_first_all[wave];
   int* lf_pref = lf_pref_all[wave];
 #define NB_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
@@ -299,11 +303,33 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
     const int i = group * 64 + lane;
     const bool live = i < n;
     const float4 me = sp[live ? i : n - 1];
-    // the group's particle positions, for the per-node minimum-distance test (padding lanes repeat a live particle).
-    // A bounding-box test would be cheaper but is pathological here: 64 CONSECUTIVE Morton-ordered particles can
-    // straddle a jump of the curve, and a box spanning the dense core forces it to be opened down to its leaves
-    // (measured: a few such groups ran 100x longer than the rest).
-    gpos[lane] = me;
+    // Acceptance volumes of the group: the bounding boxes of its 8 runs of 8 consecutive (Morton-ordered) particles. A node is accepted when
+    // l^2 < theta^2 d^2 with d the distance from its centre of mass to the NEAREST of these boxes — a lower bound of the distance to every
+    // particle of the group, so the criterion holds for each of them (conservative: never larger errors than the per-particle test, a few per
+    // cent more interactions), at 8 box tests per node instead of 64 particle tests (the exact scan was ~40 % of the walk's VALU work).
+    // 64 CONSECUTIVE Morton particles can straddle a jump of the curve; one box spanning the jump would force everything between its two
+    // ends to be opened to the leaves (measured with a single group box: a few groups ran 100x longer). A run whose box diagonal exceeds 0.6
+    // of the group's is therefore entered particle by particle (8 degenerate boxes): the list has 8 .. 64 entries, 64 being the exact test.
+    float lox = me.x, loy = me.y, loz = me.z, hix = me.x, hiy = me.y, hiz = me.z;
+#pragma unroll
+    for (int w = 1; w < 8; w <<= 1) {
+      lox = fminf(lox, __shfl_xor(lox, w)); loy = fminf(loy, __shfl_xor(loy, w)); loz = fminf(loz, __shfl_xor(loz, w));
+      hix = fmaxf(hix, __shfl_xor(hix, w)); hiy = fmaxf(hiy, __shfl_xor(hiy, w)); hiz = fmaxf(hiz, __shfl_xor(hiz, w));
+    }
+    float glx = lox, gly = loy, glz = loz, ghx = hix, ghy = hiy, ghz = hiz;
+#pragma unroll
+    for (int w = 8; w < 64; w <<= 1) {
+      glx = fminf(glx, __shfl_xor(glx, w)); gly = fminf(gly, __shfl_xor(gly, w)); glz = fminf(glz, __shfl_xor(glz, w));
+      ghx = fmaxf(ghx, __shfl_xor(ghx, w)); ghy = fmaxf(ghy, __shfl_xor(ghy, w)); ghz = fmaxf(ghz, __shfl_xor(ghz, w));
+    }
+    const float bx = hix - lox, by = hiy - loy, bz = hiz - loz, gx_ = ghx - glx, gy_ = ghy - gly, gz_ = ghz - glz;
+    const float diag2 = fmaf(bx, bx, fmaf(by, by, bz * bz)), gdiag2 = fmaf(gx_, gx_, fmaf(gy_, gy_, gz_ * gz_));
+    const bool big = diag2 > 0.36f * gdiag2;                               // same for the 8 lanes of a run
+    const bool lead = (lane & 7) == 0 && !big;
+    const unsigned long long m_lead = __ballot(lead), m_big = __ballot(big), below_l = (1ull << lane) - 1ull;
+    const int n_lead = __popcll(m_lead), nvol = n_lead + __popcll(m_big);
+    if (lead) { const int e = __popcll(m_lead & below_l); vlo[e] = make_float4(lox, loy, loz, 0.f); vhi[e] = make_float4(hix, hiy, hiz, 0.f); }
+    if (big) { const int e = n_lead + __popcll(m_big & below_l); vlo[e] = me; vhi[e] = me; }
     NB_WAVE_SYNC();
     float ax = 0.f, ay = 0.f, az = 0.f;
     int top = 1;
@@ -317,12 +343,13 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
       float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
       int4 r = make_int4(0, 0, 0, -1);
       if (v >= 0) { c = com[v]; r = rec[v]; }
-      // smallest squared distance from any particle of the group to this lane's node
+      // squared distance from this lane's node to the nearest acceptance volume of the group (wave-uniform trip count)
       float d2 = 3.4e38f;
-#pragma unroll 8
-      for (int e = 0; e < 64; ++e) {
-        const float4 g = gpos[e];                                  // LDS broadcast
-        const float ex = c.x - g.x, ey = c.y - g.y, ez = c.z - g.z;
+#pragma unroll 4
+      for (int e = 0; e < nvol; ++e) {
+        const float4 lo = vlo[e], hi = vhi[e];                        // LDS broadcasts
+        const float ex = fmaxf(fmaxf(lo.x - c.x, c.x - hi.x), 0.f), ey = fmaxf(fmaxf(lo.y - c.y, c.y - hi.y), 0.f),
+                    ez = fmaxf(fmaxf(lo.z - c.z, c.z - hi.z), 0.f);
         d2 = fminf(d2, fmaf(ex, ex, fmaf(ey, ey, ez * ez)));
       }
       const bool is_leaf = v >= n - 1;
@@ -391,7 +418,7 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
       NB_WAVE_SYNC();                          // the lists are rewritten by the next pass
     }
     if (live) { out[i] = ax; out[(size_t)n + i] = ay; out[2 * (size_t)n + i] = az; }
-    NB_WAVE_SYNC();                            // gpos is rewritten for the next group
+    NB_WAVE_SYNC();                            // the acceptance volumes are rewritten for the next group
   }
 #undef NB_WAVE_SYNC
 }
@@ -503,7 +530,7 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
     int pblocks = blocks < maxb ? blocks : maxb;            // persistent waves; groups are handed out dynamically
     if (pblocks > b.stack_blocks) pblocks = b.stack_blocks; // never more waves than wave-private stacks were allocated
     if (pblocks < 1) pblocks = 1;
-    static const int nleaf = getenv("NB_BH_NLEAF") ? atoi(getenv("NB_BH_NLEAF")) : NLEAF;
+    static const int nleaf = getenv("NB_BH_NLEAF") ? atoi(getenv("NB_BH_NLEAF")) : NLEAF_LIST;
     NB_HIP(c, hipMemsetAsync(b.flags + 1, 0, sizeof(int), st));                 // dynamic group counter
     if (eps2 > 0.f) walk_list_kernel<false><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.out, b.gstack, groups, b.flags, nleaf);
     else walk_list_kernel<true><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.out, b.gstack, groups, b.flags, nleaf);

@@ -22,6 +22,7 @@
 #include <string.h>
 
 #define NLEAF 16
+#define NLEAF_LIST 4   /* bh.hip: NLEAF_LIST */
 
 typedef struct { uint64_t key; int idx; } kv_t;
 
@@ -202,7 +203,9 @@ int bho_accel_f32(int n, const float* x, const float* y, const float* z, const f
 
 /* The LIST walk of bh.hip (walk_list_kernel), executed sequentially with the same pass structure: every pass pops up to
  * 64 nodes from the top of the stack ("lane" L takes stack[top - k + L]); a node is accepted when l^2 < theta^2 d^2 with d^2
- * the minimum over the group's particles of the squared distance to the node's centre of mass (= for EVERY particle); accepted nodes form the pass's monopole list
+ * the squared distance from the node's centre of mass to the NEAREST acceptance volume of the group: the bounding boxes of its 8 runs of 8
+ * consecutive particles, a run whose box diagonal exceeds 0.6 of the group's entered particle by particle (a lower bound of the distance
+ * to every particle: the criterion holds for EVERY particle of the group); accepted nodes form the pass's monopole list
  * (lane order), rejected nodes with <= NLEAF particles its leaf list, the others push (right, left) in lane order. Each
  * particle of the group then adds the monopoles in list order and the leaf particles in list order. */
 int bho_accel_list_f32(int n, const float* x, const float* y, const float* z, const float* m, float eps, float G,
@@ -218,6 +221,36 @@ int bho_accel_list_f32(int n, const float* x, const float* y, const float* z, co
     const int g1 = g0 + 64 < n ? g0 + 64 : n;
     float fx[64], fy[64], fz[64];
     for (int q = 0; q < 64; ++q) fx[q] = fy[q] = fz[q] = 0.f;
+    /* acceptance volumes (same arithmetic as bh.hip: min / max are exact, the diagonals are the same fmaf chains) */
+    float vlo[64][3], vhi[64][3];
+    int nvol = 0;
+    {
+      float gl[3] = {3.4e38f, 3.4e38f, 3.4e38f}, gh[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+      for (int i = g0; i < g1; ++i) {
+        const float p[3] = {t.sx[i], t.sy[i], t.sz[i]};
+        for (int c = 0; c < 3; ++c) { gl[c] = fminf(gl[c], p[c]); gh[c] = fmaxf(gh[c], p[c]); }
+      }
+      const float gx = gh[0] - gl[0], gy = gh[1] - gl[1], gz = gh[2] - gl[2];
+      const float gdiag2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
+      for (int b0 = g0; b0 < g1; b0 += 8) {
+        const int b1 = b0 + 8 < g1 ? b0 + 8 : g1;
+        float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+        for (int i = b0; i < b1; ++i) {
+          const float p[3] = {t.sx[i], t.sy[i], t.sz[i]};
+          for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], p[c]); hi[c] = fmaxf(hi[c], p[c]); }
+        }
+        const float bx = hi[0] - lo[0], by = hi[1] - lo[1], bz = hi[2] - lo[2];
+        const float diag2 = fmaf(bx, bx, fmaf(by, by, bz * bz));
+        if (diag2 > 0.36f * gdiag2) {
+          for (int i = b0; i < b1; ++i) {
+            vlo[nvol][0] = vhi[nvol][0] = t.sx[i]; vlo[nvol][1] = vhi[nvol][1] = t.sy[i]; vlo[nvol][2] = vhi[nvol][2] = t.sz[i]; ++nvol;
+          }
+        } else {
+          for (int c = 0; c < 3; ++c) { vlo[nvol][c] = lo[c]; vhi[nvol][c] = hi[c]; }
+          ++nvol;
+        }
+      }
+    }
     int top = 0;
     stack[top++] = 0;
     while (top > 0) {
@@ -231,12 +264,13 @@ int bho_accel_list_f32(int n, const float* x, const float* y, const float* z, co
         ++st[2];
         const int is_leaf = v >= n - 1;
         float d2 = 3.4e38f;
-        for (int i = g0; i < g1; ++i) {
-          const float ex = t.cx[v] - t.sx[i], ey = t.cy[v] - t.sy[i], ez = t.cz[v] - t.sz[i];
+        for (int e = 0; e < nvol; ++e) {
+          const float ex = fmaxf(fmaxf(vlo[e][0] - t.cx[v], t.cx[v] - vhi[e][0]), 0.f), ey = fmaxf(fmaxf(vlo[e][1] - t.cy[v], t.cy[v] - vhi[e][1]), 0.f),
+                      ez = fmaxf(fmaxf(vlo[e][2] - t.cz[v], t.cz[v] - vhi[e][2]), 0.f);
           d2 = fminf(d2, fmaf(ex, ex, fmaf(ey, ey, ez * ez)));
         }
         if (!is_leaf && t.l2[v] < theta2 * d2) mono[nm++] = v;
-        else if (is_leaf || t.count[v] <= NLEAF) leaf[nl++] = v;
+        else if (is_leaf || t.count[v] <= NLEAF_LIST) leaf[nl++] = v;
         else opened[no++] = v;
       }
       for (int p = 0; p < no; ++p) { stack[top + 2 * p] = t.right[opened[p]]; stack[top + 2 * p + 1] = t.left[opened[p]]; }
