@@ -266,8 +266,11 @@ constexpr int LSTACK = 12288;      // entries per wave-private stack (<= 128 nod
 // The list walk (see the header). Stack entries live in global memory (L2-resident, wave-private); entries written by
 // one lane are read by another lane of the same wave in a later pass, so every store is drained (s_waitcnt vmcnt(0))
 // before the next pass loads, and the loads bypass the vector L1.
+#ifndef NB_BH_WPE
+#define NB_BH_WPE 6                // waves per SIMD the list walk is compiled for (79 VGPRs; N = 16M: 4: 43.5 ms, 5: 42.2, 6: 41.7, 7: 41.9)
+#endif
 template <bool GUARD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_BH_WPE, NB_BH_WPE)))
 walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict__ com, const int4* __restrict__ rec,
                  float theta2, float eps2, float* __restrict__ out, int* __restrict__ gstack, int ngroups,
                  int* __restrict__ flags, int nleaf) {
