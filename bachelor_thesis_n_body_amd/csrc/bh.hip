@@ -12,8 +12,9 @@
 //   5. traversal, one 64-lane wave per group of 64 consecutive sorted particles. Two walks implement it:
 //      (list walk, default) [walk_list_kernel]: every pass pops up to 64 nodes from a wave-private stack, ONE NODE PER
 //      LANE, so 64 node records are fetched and tested at once instead of one dependent fetch per node. A node is
-//      accepted when l^2 < theta^2 d^2 for every particle of the group (d^2 = the minimum over the group's 64 particles of
-//      the squared distance to the node's centre of mass, each lane scanning the group's positions in LDS);
+//      accepted when l^2 < theta^2 d^2 for every particle of the group: d = the distance from the node's centre of mass to the nearest of
+//      the group's acceptance volumes (the bounding boxes of its 8 runs of 8 consecutive particles, in LDS; a run that straddles a jump
+//      of the Morton curve is entered particle by particle) — a lower bound of every particle's distance;
 //      wave ballots compact the accepted nodes into an LDS monopole list, rejected nodes with <= NLEAF particles into
 //      a leaf list, and push the children of the rest. Then all lanes sweep the lists for their own particle: monopoles
 //      as LDS broadcasts, leaf particles staged 64 at a time into an LDS tile (the direct kernel's inner loop).
