@@ -58,6 +58,45 @@ def measured_traffic():
         return None
 
 
+def live_traffic(args, timeout_s=150):
+    """HBM bytes per accel launch of THIS workload, measured now: two child runs of this script (one step, no CPU baseline) under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only — the guide's prescription), FETCH_SIZE doubled
+    (gfx950 reports half the bytes of wide coalesced reads: MI355X_MICROARCH.md §HBM). Children are started as subprocesses (never an exec
+    from this GPU-initialised process). Returns (bytes, note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="nb_pmc_", dir="/tmp")
+        cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, str(Path(__file__).resolve()),
+               "--steps", "1", "--warmup", "0", "--n", str(args.n), "--dtype", args.dtype, "--no-cpu-baseline", "--traffic", "none"]
+        if args.general_mass:
+            cmd.append("--general-mass")
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited with {r.returncode}"
+            per = []
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "accel_f" in row["Kernel_Name"] and "reduce" not in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        per.append(float(row["Counter_Value"]))
+            if not per:
+                return None, f"no {counter} rows for the accel kernel"
+            vals[counter] = sum(per) / len(per)
+        except (subprocess.TimeoutExpired, OSError) as e:
+            return None, f"rocprofv3 --pmc {counter}: {e}"
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate child passes of this command, 1 step), KiB x 1024, FETCH x2 (gfx950)"
+
+
 class KernelTimer:
     """HIP-event pairs around every accel launch, recorded on the stream the kernels run on (torch's current
     stream, which the engine binds with nb_set_stream)."""
@@ -211,6 +250,9 @@ def main():
                     help="drive the N GPUs from THIS process through the C-ABI's multi-device context (nb_create_multi: peer pulls of the "
                          "source blocks, no torch.distributed); with --same-device all N shards sit on GPU 0 (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic", choices=["live", "profile", "none"], default="live",
+                    help="roofline.traffic at N = 1: 'live' = measure HBM bytes per launch now with two rocprofv3 --pmc child passes (~25 s), "
+                         "falling back to the committed profile; 'profile' = the committed profile's figure; 'none' = null")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -318,9 +360,22 @@ def main():
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "flop_per_interaction": FLOP_PER_INTERACTION,
                          "interactions_per_launch": k_inter, "avg_launch_ms": k_ms, "launches_timed": k_count,
-                         "traffic": measured_traffic() if (world == 1 and args.n == 1 << 20 and args.dtype == "f32") else None,
+                         "traffic": None,
                          "traffic_source": "NOT measured in this run: HBM bytes per launch from the rocprofv3 --pmc passes of this same command committed as profiles/r02_bench_n1_uniform_rocprofv3_summary.txt (FETCH_SIZE x2 + WRITE_SIZE; 0.4 GB = the fp64 slab of the 8-way source split); algorithmic bytes = 28*N"},
         }
+        r = out["roofline"]
+        profile_note = r["traffic_source"]
+        r["algorithmic_bytes_per_launch"] = (28 if args.dtype == "f32" else 56) * args.n
+        if world > 1 or args.traffic == "none":
+            r["traffic_source"] = "not collected (N > 1 or --traffic none)"
+        else:
+            got, note = live_traffic(args) if args.traffic == "live" else (None, "--traffic profile")
+            if got is not None:
+                r["traffic"], r["traffic_source"] = got, note
+            elif args.n == 1 << 20 and args.dtype == "f32" and not args.general_mass:
+                r["traffic"], r["traffic_source"] = measured_traffic(), profile_note + f" [live measurement unavailable: {note}]"
+            else:
+                r["traffic_source"] = f"not available: {note}"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(state, eps)
         print(json.dumps(out), flush=True)

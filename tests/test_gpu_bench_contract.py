@@ -29,6 +29,9 @@ def test_bench_prints_one_contract_json_line():
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["value"] < j["value"]
     assert r["variant"] == "uniform_mass" and j["world_size"] == 1 and j["ring"] is None
+    # HBM traffic measured live (two rocprofv3 --pmc child passes of the same command), not read from a committed file
+    assert r["traffic_source"].startswith("measured in this run"), r["traffic_source"]
+    assert r["traffic"] > r["algorithmic_bytes_per_launch"] == 28 * 65536
 
 
 def test_bench_general_mass_variant_is_labelled():
