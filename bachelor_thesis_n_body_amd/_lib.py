@@ -35,6 +35,7 @@ SIGNATURES = {
     "nb_set_mesh": (_int, [_vp, _int, _dbl, _int, _dbl, _dbl, _int]),
     "nb_kdk_step": (_int, [_vp, _dbl, _dbl, _dbl, _dbl, _dbl]),
     "nb_kdk_run": (_int, [_vp, _i64, _vp, _vp, _vp, _dbl, _dbl]),
+    "nb_rung_step": (_int, [_vp, _int, _vp, _vp, _dbl, _dbl, _dbl, _dbl, C.POINTER(_i64)]),
     "nb_last_run_used_graph": (_int, [_vp]),
     "nb_set_state": (_int, [_vp] + [_vp] * 7),
     "nb_get_state": (_int, [_vp] + [_vp] * 7),

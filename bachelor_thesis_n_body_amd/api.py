@@ -90,6 +90,17 @@ class Engine:
         _lib.check(self._ctx, self._lib.nb_kdk_run(self._ctx, k1.size, k1.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
                                                    k2.ctypes.data_as(C.c_void_p), eps, G), "nb_kdk_run")
 
+    def rung_step(self, levels: int, kc, dc, dt_base: float, crit: float, eps: float, G: float = 1.0):
+        """One base step with a rung hierarchy for the short-range force (nb_rung_step; P3M contexts). Returns the rung populations."""
+        kc, dc = np.ascontiguousarray(kc, np.float64), np.ascontiguousarray(dc, np.float64)
+        need = 2 * (1 << (int(levels) - 1)) + 1
+        if kc.shape != (need,) or dc.shape != (need,):
+            raise ValueError(f"kc and dc must have {need} entries for {levels} levels")
+        pop = (C.c_int64 * 8)()
+        _lib.check(self._ctx, self._lib.nb_rung_step(self._ctx, int(levels), _ptr(kc), _ptr(dc), float(dt_base), float(crit), float(eps), float(G), pop),
+                   "nb_rung_step")
+        return [int(v) for v in pop[: int(levels)]]
+
     def last_run_used_graph(self) -> bool:
         """True if the last kdk_run() replayed a captured hipGraph of one step (small-N, launch-bound runs)."""
         return bool(self._lib.nb_last_run_used_graph(self._ctx))

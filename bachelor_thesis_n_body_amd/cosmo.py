@@ -63,6 +63,26 @@ class Cosmology:
         from scipy.optimize import brentq
         return float(brentq(lambda a: self.cosmic_time(a) - float(t), 1e-8, 4.0, xtol=1e-15, rtol=1e-13))
 
+    def _clock_table(self):
+        """(ln a, t) on 40 000 points from a = 1e-5 to 3: cumulative Simpson-like integral of dt = dln a / H, anchored by one exact quadrature.
+        Interpolating it gives t(a) and a(t) to ~1e-9 relative — what the schedule code calls hundreds of times per run."""
+        tab = self.__dict__.get("_clock")
+        if tab is None:
+            la = np.linspace(np.log(1e-5), np.log(3.0), 40001)
+            f = 1.0 / self.H(np.exp(la))
+            mid = 1.0 / self.H(np.exp(0.5 * (la[:-1] + la[1:])))
+            t = self.cosmic_time(1e-5) + np.concatenate([[0.0], np.cumsum((f[:-1] + 4.0 * mid + f[1:]) * (la[1] - la[0]) / 6.0)])
+            tab = self.__dict__["_clock"] = (la, t)
+        return tab
+
+    def scale_factor_fast(self, t):
+        la, tt = self._clock_table()
+        return np.exp(np.interp(t, tt, la))
+
+    def cosmic_time_fast(self, a):
+        la, tt = self._clock_table()
+        return np.interp(np.log(a), la, tt)
+
     def growth(self, a: float):
         """(D(a) with D(1) = 1, f = dlnD/dlna) of sub-horizon matter perturbations, from the linear growth ODE
             D'' + (2 + dlnH/dlna) D' - (3/2) Omega_m(a) D = 0      (' = d/dlna)
@@ -202,7 +222,7 @@ def concept_time_edges(cosmo: Cosmology, a_begin: float, a_end: float, dt_steps)
     """Step boundaries in COSMIC TIME for a run from a_begin to a_end that takes CONCEPT's logged step sizes `dt_steps` [Gyr] in
     order (the last step is cut at t(a_end), as CONCEPT cuts its last step at an output time; steps beyond a_end are dropped; if the
     sizes run out before a_end the last one is repeated)."""
-    t0, t1 = cosmo.cosmic_time(a_begin), cosmo.cosmic_time(a_end)
+    t0, t1 = float(cosmo.cosmic_time_fast(a_begin)), float(cosmo.cosmic_time_fast(a_end))
     edges, k = [t0], 0
     dts = [float(v) for v in dt_steps]
     while edges[-1] < t1 * (1.0 - 1e-12):
@@ -244,9 +264,9 @@ def run_pp(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: flo
         else:
             dts = np.asarray(schedule, np.float64)
         t_edges = concept_time_edges(cosmo, a_begin, a_end, dts)
-        edges = np.array([cosmo.scale_factor(t) for t in t_edges])
+        edges = np.asarray(cosmo.scale_factor_fast(t_edges), np.float64).copy()
         edges[0], edges[-1] = a_begin, a_end
-        mids = np.array([cosmo.scale_factor(0.5 * (ta + tb)) for ta, tb in zip(t_edges[:-1], t_edges[1:])])
+        mids = np.asarray(cosmo.scale_factor_fast(0.5 * (t_edges[:-1] + t_edges[1:])), np.float64)
     if gravity not in ("pp", "pm", "p3m"):
         raise ValueError("gravity must be 'pp', 'pm' or 'p3m'")
     with Engine(n, dtype, device) as e:
@@ -270,6 +290,42 @@ def run_pp(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: flo
 
 
 run_nbody = run_pp          # the name that fits all three solvers
+
+
+def run_rungs(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: float, a_end: float = 1.0, schedule="concept",
+              eta: float = 0.025, levels: int = 5, eps: Optional[float] = None, ngrid: Optional[int] = None, interlace: bool = True,
+              scale_cells: float = 1.25, range_scales: float = 4.5, device: int = 0, dtype=np.float32, return_populations: bool = False):
+    """Comoving P3M run with CONCEPT's time-loop structure: base steps from `schedule` ("concept" = the steps its logs
+    record, or an array of step sizes in Gyr), the mesh force kicking every particle once per base step, the short-range force through a
+    rung hierarchy — a particle on rung l takes short-range kick-drift-kick steps of dt_base / 2^l (`nb_rung_step`). Rung limiter: the usual
+    dt_i = sqrt(2 eta eps_phys / |a_phys|) with physical softening a*eps and peculiar acceleration g / a^2, i.e. dt_i^2 = 2 eta eps a^3 / |g| in the code's
+    variables; `eta` is calibrated against the rung populations the reference's logs record (tests/test_gpu_rungs.py). Returns (pos, vel[, populations per step])."""
+    from .api import Engine
+    from .state import State
+    n = pos.shape[0]
+    if eps is None:
+        eps = 0.03 * boxsize / round(n ** (1.0 / 3.0))
+    if isinstance(schedule, str) and schedule == "concept":
+        a_fix, _, dts = load_concept_schedule()
+        dts = dts[max(0, int(np.searchsorted(a_fix, a_begin * (1.0 + 1e-4), side="right")) - 1):]
+    else:
+        dts = np.asarray(schedule, np.float64)
+    t_edges = concept_time_edges(cosmo, a_begin, a_end, dts)
+    half = 2 * (1 << (levels - 1))
+    pops = []
+    with Engine(n, dtype, device) as e:
+        cb = round(n ** (1.0 / 3.0))
+        e.set_mesh("p3m", boxsize, int(ngrid) if ngrid else cb, scale_cells, range_scales, interlace)
+        e.set_state(State(np.asarray(pos, dtype), np.asarray(vel, dtype), np.full(n, mass, dtype)))
+        for t0, t1 in zip(t_edges[:-1], t_edges[1:]):
+            ab = np.asarray(cosmo.scale_factor_fast(np.linspace(t0, t1, half + 1)), np.float64)
+            kc = np.concatenate([[0.0], np.cumsum([cosmo.kick_factor(x, y, 9) for x, y in zip(ab[:-1], ab[1:])])])
+            dc = np.concatenate([[0.0], np.cumsum([cosmo.drift_factor(x, y, 9) for x, y in zip(ab[:-1], ab[1:])])])
+            a_mid = ab[half // 2]
+            pops.append(e.rung_step(levels, kc, dc, t1 - t0, 2.0 * eta * eps * a_mid ** 3, eps, _params.G_NEWTON))
+        st = e.get_state()
+    out = (st.pos.astype(np.float64), st.vel.astype(np.float64))
+    return out + (np.array(pops),) if return_populations else out
 
 
 def power_modes(pos, boxsize: float, ngrid: int, interlace: bool = True):

@@ -137,6 +137,10 @@ int nb_destroy(nb_ctx* c) {
   if (c->scal) (void)hipFree(c->scal);
   if (c->phi) (void)hipFree(c->phi);
   if (c->elog) (void)hipFree(c->elog);
+  if (c->acc_lr) (void)hipFree(c->acc_lr);
+  if (c->rung) (void)hipFree(c->rung);
+  if (c->rung_hist) (void)hipFree(c->rung_hist);
+  if (c->rung_tab) (void)hipFree(c->rung_tab);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return NB_OK;
@@ -192,6 +196,7 @@ int nb_set_mesh(nb_ctx* c, int solver, double boxsize, int ngrid, double scale_c
   }
   if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
   c->acc_valid = false;
+  c->lr_valid = false;
   c->solver = solver; c->box = boxsize; c->mesh_grid = ngrid; c->mesh_scale = scale_cells; c->mesh_range = range_scales;
   c->mesh_interlace = (flags & NB_MESH_NO_INTERLACE) ? 0 : 1;
   c->mesh_parts = (flags & NB_MESH_LONG_ONLY) ? 1 : (flags & NB_MESH_SHORT_ONLY) ? 2 : 3;
@@ -218,6 +223,7 @@ int nb_set_state(nb_ctx* c, const void* x, const void* y, const void* z, const v
   for (int f = 0; f < 7; ++f) NB_HIP(c, hipMemcpyAsync(base + (size_t)f * b, src[f], b, hipMemcpyHostToDevice, c->stream));
   NB_HIP(c, hipStreamSynchronize(c->stream));
   c->acc_valid = false;
+  c->lr_valid = false;
   c->has_state = true;
   // a captured step graph bakes in the UNIFORM / general-mass kernel variant chosen for the previous masses
   if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
@@ -246,6 +252,7 @@ int nb_get_state(nb_ctx* c, void* x, void* y, void* z, void* vx, void* vy, void*
 // a(x) of the context's own particles into the state's ax/ay/az fields
 static int refresh_acc(nb_ctx* c, double eps, double G, double* phi = nullptr) {
   int rc;
+  c->lr_valid = false;      // the acc arrays are about to hold the TOTAL force again (nb_rung_step keeps the short-range part there)
   if (phi && c->solver != NB_SOLVER_DIRECT) return nb_fail(c, NB_ERR_ARG, "the fused potential needs the direct solver");
   if (c->solver == NB_SOLVER_EWALD) {
     const size_t b = (size_t)c->n * esize(c->dtype);
@@ -454,6 +461,78 @@ int nb_kdk_run(nb_ctx* c, int64_t nsteps, const double* kick1, const double* dri
   for (int64_t k = k0; k < nsteps; ++k) { rc = kdk_enqueue(c, kick1[k], drift[k], kick2[k], eps, G); if (rc) return rc; }
   NB_HIP(c, hipStreamSynchronize(c->stream));       // the only host round trip of the run
   return nb_bh_check(c);
+}
+
+// One base step with a rung hierarchy for the short-range force of a P3M context — the structure CONCEPT's logs show for every base step
+// (…/params_id0200_*.log:56-96: long-range kick, short-range kick, "Intertwining drifts of matter with the following particle interactions: short-range",
+// long-range kick): the long-range (mesh) force kicks every particle over the base step; each particle sits on rung l and receives its short-range
+// kicks in steps of dt_base / 2^l; all particles drift with the finest populated step and the short-range force is re-evaluated after every drift.
+int nb_rung_step(nb_ctx* c, int levels, const double* kc, const double* dc, double dt_base, double crit, double eps, double G,
+                 int64_t* populations) {
+  if (!c) return NB_ERR_ARG;
+  if (c->multi) return nb_fail(c, NB_ERR_ARG, "nb_rung_step: not available on a multi-device context");
+  if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_rung_step: call nb_set_state first");
+  if (c->solver != NB_SOLVER_P3M) return nb_fail(c, NB_ERR_ARG, "nb_rung_step: needs a P3M context (nb_set_mesh): the rungs belong to the short-range force");
+  if (levels < 1 || levels > 8 || !kc || !dc) return nb_fail(c, NB_ERR_ARG, "nb_rung_step: levels must be in [1, 8], tables non-NULL");
+  if (!(eps >= 0.0) || !(dt_base > 0.0) || !(crit > 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_rung_step: eps >= 0, dt_base > 0, crit > 0");
+  int rc = use_device(c); if (rc) return rc;
+  const size_t b = (size_t)c->n * esize(c->dtype);
+  char* s = reinterpret_cast<char*>(c->state);
+  void *x = s, *y = s + b, *z = s + 2 * b, *m = s + 3 * b, *vx = s + 4 * b, *vy = s + 5 * b, *vz = s + 6 * b, *ax = s + 7 * b, *ay = s + 8 * b, *az = s + 9 * b;
+  const int Smax = 1 << (levels - 1);
+  const size_t tab_len = 2 * (size_t)(2 * Smax + 1);
+  if (!c->acc_lr) NB_HIP(c, hipMalloc(&c->acc_lr, 3 * b));
+  if (!c->rung) NB_HIP(c, hipMalloc((void**)&c->rung, (size_t)c->n));
+  if (!c->rung_hist) NB_HIP(c, hipMalloc((void**)&c->rung_hist, 16 * sizeof(int)));
+  if (c->rung_tab_len < tab_len) {
+    NB_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->rung_tab) (void)hipFree(c->rung_tab);
+    c->rung_tab = nullptr; c->rung_tab_len = 0;
+    NB_HIP(c, hipMalloc((void**)&c->rung_tab, tab_len * sizeof(double)));
+    c->rung_tab_len = tab_len;
+  }
+  auto force = [&](int parts) -> int {     // parts: 1 = mesh only, 2 = pairs only; result in the state's acc arrays
+    return nb_launch_accel_mesh(c, c->dtype, x, y, z, m, c->n, c->box, c->mesh_grid, c->mesh_scale, c->mesh_range, 1, c->mesh_interlace, parts,
+                                eps * eps, G, ax, ay, az);
+  };
+  c->acc_valid = false;                    // the state's acc arrays hold the short-range part only from here on
+  if (!c->lr_valid) {
+    rc = force(1); if (rc) return rc;
+    NB_HIP(c, hipMemcpyAsync(c->acc_lr, ax, 3 * b, hipMemcpyDeviceToDevice, c->stream));
+    rc = force(2); if (rc) return rc;
+    c->lr_valid = true;
+  }
+  // rungs from the total acceleration at the start of the base step
+  NB_HIP(c, hipMemsetAsync(c->rung_hist, 0, 16 * sizeof(int), c->stream));
+  rc = nb_launch_rung_assign(c, c->dtype, ax, c->acc_lr, c->n, dt_base, crit, levels, c->rung, c->rung_hist); if (rc) return rc;
+  int hist[16];
+  NB_HIP(c, hipMemcpyAsync(hist, c->rung_hist, sizeof(hist), hipMemcpyDeviceToHost, c->stream));
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  int top = 0;
+  for (int l = 0; l < levels; ++l) { if (populations) populations[l] = hist[l]; if (hist[l] > 0) top = l; }
+  const int S = 1 << top, stride = Smax / S;      // sub-steps actually taken; the tables are given at the finest possible resolution
+  // tables at the resolution in use (host side: tiny)
+  std::vector<double> k2(2 * S + 1), d2(2 * S + 1);
+  for (int j = 0; j <= 2 * S; ++j) { k2[j] = kc[j * stride]; d2[j] = dc[j * stride]; }
+  NB_HIP(c, hipMemcpyAsync(c->rung_tab, k2.data(), k2.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  const double* dkc = c->rung_tab;
+  // long-range half kick for everybody
+  rc = nb_launch_kick(c, c->dtype, vx, vy, vz, c->acc_lr, (char*)c->acc_lr + b, (char*)c->acc_lr + 2 * b, c->n, k2[S] - k2[0]); if (rc) return rc;
+  for (int sub = 0; sub < S; ++sub) {
+    rc = nb_launch_rung_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->rung, c->n, 0, sub, S, top, dkc); if (rc) return rc;
+    rc = nb_launch_drift(c, c->dtype, x, y, z, vx, vy, vz, c->n, d2[2 * sub + 2] - d2[2 * sub]); if (rc) return rc;
+    rc = nb_launch_wrap(c, c->dtype, x, y, z, c->n, c->box); if (rc) return rc;
+    if (sub == S - 1) {                    // end of the base step: the mesh force of the new positions, kept apart
+      rc = force(1); if (rc) return rc;
+      NB_HIP(c, hipMemcpyAsync(c->acc_lr, ax, 3 * b, hipMemcpyDeviceToDevice, c->stream));
+    }
+    rc = force(2); if (rc) return rc;
+    rc = nb_launch_rung_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->rung, c->n, 1, sub, S, top, dkc); if (rc) return rc;
+  }
+  rc = nb_launch_kick(c, c->dtype, vx, vy, vz, c->acc_lr, (char*)c->acc_lr + b, (char*)c->acc_lr + 2 * b, c->n, k2[2 * S] - k2[S]); if (rc) return rc;
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  return NB_OK;
 }
 
 int nb_last_run_used_graph(const nb_ctx* c) { return c ? (c->graph_replayed ? 1 : 0) : NB_ERR_ARG; }

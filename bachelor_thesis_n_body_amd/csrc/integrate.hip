@@ -75,6 +75,48 @@ kdk_post_kernel(T* __restrict__ vx, T* __restrict__ vy, T* __restrict__ vz, cons
   }
 }
 
+// ---- rung hierarchy (nb_rung_step): per-particle rungs for the short-range force, as in CONCEPT's time loop
+// rung_i = the lowest rung l < levels with dt_base / 2^l <= sqrt(crit / |g_i|), g = a_sr + a_lr; hist[l] counts the populations.
+template <typename T>
+__global__ void __launch_bounds__(256)
+rung_assign_kernel(const T* __restrict__ sx, const T* __restrict__ sy, const T* __restrict__ sz, const T* __restrict__ lx,
+                   const T* __restrict__ ly, const T* __restrict__ lz, int64_t n, double dt_base, double crit, int levels,
+                   unsigned char* __restrict__ rung, int* __restrict__ hist) {
+  __shared__ int h[16];
+  if (threadIdx.x < 16) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double gx = (double)sx[i] + (double)lx[i], gy = (double)sy[i] + (double)ly[i], gz = (double)sz[i] + (double)lz[i];
+    const double g = sqrt(gx * gx + gy * gy + gz * gz);
+    const double dti = g > 0.0 ? sqrt(crit / g) : 1e300;
+    int l = 0;
+    double dt = dt_base;
+    while (l < levels - 1 && dt > dti) { dt *= 0.5; ++l; }
+    rung[i] = (unsigned char)l;
+    atomicAdd(&h[l], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// short-range kicks of sub-step s of S (finest level): phase 0 = opening half-kick of every rung whose step BEGINS at s, phase 1 = closing half-kick of
+// every rung whose step ENDS at s + 1. kc = cumulative kick integral at the 2 S + 1 half-sub-step boundaries of the base step (device, double).
+template <typename T>
+__global__ void __launch_bounds__(256)
+rung_kick_kernel(T* __restrict__ vx, T* __restrict__ vy, T* __restrict__ vz, const T* __restrict__ ax, const T* __restrict__ ay,
+                 const T* __restrict__ az, const unsigned char* __restrict__ rung, int64_t n, int phase, int s, int S, int top,
+                 const double* __restrict__ kc) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int l = rung[i];
+    l = l > top ? top : l;
+    const int len = S >> l;                      // the rung's step in finest sub-steps
+    T h;
+    if (phase == 0) { if (s % len) continue; h = (T)(kc[2 * s + len] - kc[2 * s]); }
+    else { if ((s + 1) % len) continue; h = (T)(kc[2 * (s + 1)] - kc[2 * (s + 1) - len]); }
+    vx[i] = vx[i] + ax[i] * h; vy[i] = vy[i] + ay[i] * h; vz[i] = vz[i] + az[i] * h;
+  }
+}
+
 __global__ void kdk_advance_kernel(int* __restrict__ step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
 
 // per-block fp64 partial of sum m v^2 / 2 -> part[blockIdx.x]; fixed-order final pass below
@@ -198,6 +240,32 @@ int nb_launch_kick_drift(nb_ctx* c, int dtype, void* x, void* y, void* z, void* 
     kick_drift_kernel<double><<<stream_grid(n), 256, 0, c->stream>>>(
         (double*)x, (double*)y, (double*)z, (double*)vx, (double*)vy, (double*)vz, (const double*)ax,
         (const double*)ay, (const double*)az, n, h1, h2, dt, two);
+  NB_HIP(c, hipGetLastError());
+  return NB_OK;
+}
+
+int nb_launch_rung_assign(nb_ctx* c, int dtype, const void* sr, const void* lr, int64_t n, double dt_base, double crit, int levels,
+                          unsigned char* rung, int* hist) {
+  const size_t es = dtype == NB_F64 ? 8 : 4;
+  const char *s = (const char*)sr, *l = (const char*)lr;
+  if (dtype == NB_F32)
+    rung_assign_kernel<float><<<stream_grid(n), 256, 0, c->stream>>>((const float*)s, (const float*)(s + n * es), (const float*)(s + 2 * n * es),
+                                                                     (const float*)l, (const float*)(l + n * es), (const float*)(l + 2 * n * es), n, dt_base, crit, levels, rung, hist);
+  else
+    rung_assign_kernel<double><<<stream_grid(n), 256, 0, c->stream>>>((const double*)s, (const double*)(s + n * es), (const double*)(s + 2 * n * es),
+                                                                      (const double*)l, (const double*)(l + n * es), (const double*)(l + 2 * n * es), n, dt_base, crit, levels, rung, hist);
+  NB_HIP(c, hipGetLastError());
+  return NB_OK;
+}
+
+int nb_launch_rung_kick(nb_ctx* c, int dtype, void* vx, void* vy, void* vz, const void* ax, const void* ay, const void* az,
+                        const unsigned char* rung, int64_t n, int phase, int s, int S, int top, const double* kc) {
+  if (dtype == NB_F32)
+    rung_kick_kernel<float><<<stream_grid(n), 256, 0, c->stream>>>((float*)vx, (float*)vy, (float*)vz, (const float*)ax, (const float*)ay, (const float*)az,
+                                                                   rung, n, phase, s, S, top, kc);
+  else
+    rung_kick_kernel<double><<<stream_grid(n), 256, 0, c->stream>>>((double*)vx, (double*)vy, (double*)vz, (const double*)ax, (const double*)ay, (const double*)az,
+                                                                    rung, n, phase, s, S, top, kc);
   NB_HIP(c, hipGetLastError());
   return NB_OK;
 }

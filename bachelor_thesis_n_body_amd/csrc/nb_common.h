@@ -32,6 +32,13 @@ struct nb_ctx {
   // one KDK step [kick_drift(h,h,dt); a(x)] captured as a hipGraph and replayed for launch-bound (small-N) runs
   hipGraphExec_t step_graph = nullptr;
   double graph_dt = 0.0, graph_eps = -1.0, graph_G = 0.0;
+  // rung hierarchy (nb_rung_step): long-range acceleration kept apart from the short-range one, per-particle rungs, population histogram, tables
+  void* acc_lr = nullptr;
+  unsigned char* rung = nullptr;
+  int* rung_hist = nullptr;          // 16 device ints
+  double* rung_tab = nullptr;        // kick + drift tables of one base step (device)
+  size_t rung_tab_len = 0;
+  bool lr_valid = false;             // acc_lr / the state's acc hold a_lr / a_sr of the current positions
   bool graph_replayed = false;   // the last nb_kdk_run replayed a captured step (diagnostic: nb_last_run_used_graph)
   // force solver used by nb_accel / nb_step: direct summation (default) or Barnes-Hut tree (fp32 only)
   int solver = 0;
@@ -113,6 +120,10 @@ int nb_launch_kick(nb_ctx* c, int dtype, void* vx, void* vy, void* vz, const voi
                    const void* az, int64_t n, double h);
 int nb_launch_drift(nb_ctx* c, int dtype, void* x, void* y, void* z, const void* vx, const void* vy,
                     const void* vz, int64_t n, double dt);
+int nb_launch_rung_assign(nb_ctx* c, int dtype, const void* sr, const void* lr, int64_t n, double dt_base, double crit, int levels,
+                          unsigned char* rung, int* hist);
+int nb_launch_rung_kick(nb_ctx* c, int dtype, void* vx, void* vy, void* vz, const void* ax, const void* ay, const void* az,
+                        const unsigned char* rung, int64_t n, int phase, int s, int S, int top, const double* kc);
 // phase 0: v += a*fac[3s]; x += v*fac[3s+1]   phase 1: v += a*fac[3s+2]; ++s      with s = *step read on the device (graph-replayable KDK)
 int nb_launch_kdk_indexed(nb_ctx* c, int dtype, int phase, void* x, void* y, void* z, void* vx, void* vy, void* vz,
                           const void* ax, const void* ay, const void* az, int64_t n, const double* fac, int* step);

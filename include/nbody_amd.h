@@ -110,6 +110,15 @@ int nb_kdk_step(nb_ctx* ctx, double kick1, double drift, double kick2, double ep
 /* nsteps generalised KDK steps with per-step factors (host arrays of nsteps doubles), enqueued back to back: one host
  * synchronisation for the whole run — a comoving run from a_begin to an output time is one call */
 int nb_kdk_run(nb_ctx* ctx, int64_t nsteps, const double* kick1, const double* drift, const double* kick2, double eps, double G);
+/* One BASE step of a comoving P3M run with a rung hierarchy for the short-range force — the structure of CONCEPT's time loop as its logs show it
+ * (…/params_id0200_*.log:56-96): the mesh force kicks every particle over the base step (half at its start, half at its end); a
+ * particle on rung l receives its short-range kicks in steps of dt_base / 2^l (kick-drift-kick per rung step); all particles drift with the finest
+ * populated step and the short-range force is re-evaluated after every drift. Rungs are assigned at the start of the step from the total acceleration
+ * g = a_sr + a_lr: the lowest l < levels with dt_base / 2^l <= sqrt(crit / |g|)  (crit = 2 eta eps a^3 for the usual sqrt(2 eta eps_phys / |a_phys|) limiter in
+ * the comoving variables of nb_kdk_step). kc / dc: the cumulative kick integral int dt/a and drift integral int dt/a^2 from the start of the base step to each
+ * of the 2 * 2^(levels-1) + 1 boundaries of its finest half-sub-steps (host arrays). populations[l] (may be NULL) returns the rung populations. P3M contexts only. */
+int nb_rung_step(nb_ctx* ctx, int levels, const double* kc, const double* dc, double dt_base, double crit, double eps, double G,
+                 int64_t* populations);
 /* 1 if the last nb_kdk_run replayed a captured hipGraph of one step (n <= 300 000 particles and >= 8 steps: the launch-bound regime of the
  * thesis' 32^3 / 64^3 farm jobs — the step's kick/drift factors are read from a device table indexed by a device-side step counter, so every
  * step is the same launch sequence), 0 if it launched every step eagerly (large n, NB_NO_GRAPH set, the NULL stream, or a capture the

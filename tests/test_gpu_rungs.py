@@ -1,0 +1,57 @@
+"""nb_rung_step / cosmo.run_rungs — CONCEPT's time-loop structure: base steps from the reference's logs, the mesh
+force once per base step, the short-range force through a rung hierarchy. Pins: (i) with a single level it IS the plain KDK of nb_kdk_step
+over the same steps; (ii) the rung populations against the ones the reference's logs record; (iii) with the hierarchy the small-scale power
+lost by CONCEPT's coarse base steps comes back."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from bachelor_thesis_n_body_amd import cosmo
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden" / "concept"
+
+
+def _setup(n_side, seed):
+    ref = np.loadtxt(GOLD / "PP_powerspec_a=1.00")
+    k_ref, p_lin = ref[:, 0], ref[:, 4]
+    slope = np.log(p_lin[-1] / p_lin[-3]) / np.log(k_ref[-1] / k_ref[-3])
+    k_ext = np.geomspace(k_ref[-1] * 1.05, 1.0, 12)
+    tab = np.column_stack([np.concatenate([k_ref, k_ext]), np.concatenate([p_lin, p_lin[-1] * (k_ext / k_ref[-1]) ** slope])])
+    c = cosmo.Cosmology.from_h_omegas(0.6736, 0.02237, 0.12)
+    pos, vel = cosmo.zeldovich_ics(tab, n_side, 500.0, c, 0.02, seed, seed + 50, lpt=1)
+    return c, pos, vel
+
+
+def test_one_level_is_the_plain_kdk_over_the_same_steps():
+    c, pos, vel = _setup(16, 3)
+    m = c.particle_mass(500.0, 16 ** 3)
+    p1, v1 = cosmo.run_pp(pos, vel, m, 500.0, c, 0.02, 0.2, dtype=np.float64, gravity="p3m", ngrid=16, schedule="concept")
+    p2, v2, pops = cosmo.run_rungs(pos, vel, m, 500.0, c, 0.02, 0.2, levels=1, dtype=np.float64, ngrid=16, return_populations=True)
+    assert np.all(pops[:, 0] == 16 ** 3)
+    d = np.abs(p1 - p2); d = np.minimum(d, 500.0 - d)
+    assert d.max() < 1e-6 and np.abs(v1 - v2).max() < 1e-8 * np.abs(v1).max() + 1e-12       # mesh + pairs evaluated apart vs together: round-off
+
+
+def test_rung_populations_follow_the_reference_logs_and_restore_small_scale_power():
+    """32^3 p3m farm job (NN.param) on CONCEPT's own base steps. The logs (concept_step_schedule.txt, column 7) record the mean fraction of particles above rung 0:
+    0 until a ~ 0.25, 0.8 % at a = 0.46, 2.5 % at 0.57, 5.2 % at 0.70, 5.8 % at a = 1."""
+    sched = np.loadtxt(GOLD / "concept_step_schedule.txt")
+    frac_ref = sched[:, 6]
+    c, pos, vel = _setup(32, 11)
+    m = c.particle_mass(500.0, 32 ** 3)
+    p_r, _, pops = cosmo.run_rungs(pos, vel, m, 500.0, c, 0.02, 1.0, levels=5, return_populations=True)
+    assert pops.shape == (143, 5) and np.all(pops.sum(1) == 32 ** 3)
+    frac = 1.0 - pops[:, 0] / 32 ** 3
+    assert np.all(frac[:80] < 2e-3)                                              # everybody on rung 0 while the field is smooth
+    assert frac[-1] == pytest.approx(frac_ref[-1], rel=0.5) and frac[120] == pytest.approx(frac_ref[120], rel=0.6)
+    assert np.all(np.diff(frac[96:128:8]) > 0)                                   # and the population of the higher rungs grows as structure forms
+    # same base steps without the hierarchy vs with it vs the step-converged run: the hierarchy recovers the small-scale power
+    p_0, _ = cosmo.run_pp(pos, vel, m, 500.0, c, 0.02, 1.0, dtype=np.float32, gravity="p3m", ngrid=32, schedule="concept")
+    p_c, _ = cosmo.run_pp(pos, vel, m, 500.0, c, 0.02, 1.0, nsteps=600, dtype=np.float32, gravity="p3m", ngrid=32)
+    top = lambda p: cosmo.power_modes(p, 500.0, 32, interlace=True)
+    k, pk_c = top(p_c); _, pk_0 = top(p_0); _, pk_r = top(p_r)
+    hi = k > 0.15
+    r0, rr = pk_0[hi].mean() / pk_c[hi].mean(), pk_r[hi].mean() / pk_c[hi].mean()
+    assert r0 < 0.985 and abs(rr - 1.0) < abs(r0 - 1.0) * 0.6, (r0, rr)

@@ -53,10 +53,10 @@ def test_schedule_reconstruction_reproduces_the_logged_scale_factors():
     assert len(edges_t) == 144                                     # 143 steps, the last one cut at a = 1
     a_edges = np.array([C.scale_factor(x) for x in edges_t])
     np.testing.assert_allclose(a_edges[:-1], a, rtol=6e-4)          # the log prints 4 digits of dt: 4e-4 accumulated
-    assert a_edges[-1] == pytest.approx(1.0, abs=1e-9)
+    assert a_edges[-1] == pytest.approx(1.0, abs=1e-7)                  # the schedule code interpolates a 40 000-point clock table (~1e-8)
     # a run that stops early takes the same steps and cuts the last one
     e2 = cosmo.concept_time_edges(C, 0.02, 0.5, dt)
-    assert np.all(e2[:-1] == edges_t[:len(e2) - 1]) and C.scale_factor(e2[-1]) == pytest.approx(0.5, rel=1e-9)
+    assert np.all(e2[:-1] == edges_t[:len(e2) - 1]) and C.scale_factor(e2[-1]) == pytest.approx(0.5, rel=1e-7)
 
 
 @pytest.mark.parametrize("name", ["PP", "PM", "P3M"])
