@@ -27,8 +27,8 @@ def _setup(n_side, seed):
 def test_one_level_is_the_plain_kdk_over_the_same_steps():
     c, pos, vel = _setup(16, 3)
     m = c.particle_mass(500.0, 16 ** 3)
-    p1, v1 = cosmo.run_pp(pos, vel, m, 500.0, c, 0.02, 0.2, dtype=np.float64, gravity="p3m", ngrid=16, schedule="concept")
-    p2, v2, pops = cosmo.run_rungs(pos, vel, m, 500.0, c, 0.02, 0.2, levels=1, dtype=np.float64, ngrid=16, return_populations=True)
+    p1, v1 = cosmo.run_pp(pos, vel, m, 500.0, c, 0.02, 0.2, dtype=np.float64, gravity="p3m", ngrid=32, schedule="concept")
+    p2, v2, pops = cosmo.run_rungs(pos, vel, m, 500.0, c, 0.02, 0.2, levels=1, dtype=np.float64, ngrid=32, return_populations=True)
     assert np.all(pops[:, 0] == 16 ** 3)
     d = np.abs(p1 - p2); d = np.minimum(d, 500.0 - d)
     assert d.max() < 1e-6 and np.abs(v1 - v2).max() < 1e-8 * np.abs(v1).max() + 1e-12       # mesh + pairs evaluated apart vs together: round-off
