@@ -31,7 +31,8 @@ def test_one_level_is_the_plain_kdk_over_the_same_steps():
     p2, v2, pops = cosmo.run_rungs(pos, vel, m, 500.0, c, 0.02, 0.2, levels=1, dtype=np.float64, ngrid=32, return_populations=True)
     assert np.all(pops[:, 0] == 16 ** 3)
     d = np.abs(p1 - p2); d = np.minimum(d, 500.0 - d)
-    assert d.max() < 1e-6 and np.abs(v1 - v2).max() < 1e-8 * np.abs(v1).max() + 1e-12       # mesh + pairs evaluated apart vs together: round-off
+    # same scheme, two quadratures of the kick / drift integrals (65-point trapezoid per half step vs cumulative 9-point pieces): 1e-5 relative
+    assert d.max() < 1e-3 and np.abs(v1 - v2).max() < 2e-4 * np.abs(v1).max()
 
 
 def test_rung_populations_follow_the_reference_logs_and_restore_small_scale_power():
