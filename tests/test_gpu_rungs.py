@@ -46,8 +46,13 @@ def test_rung_populations_follow_the_reference_logs_and_restore_small_scale_powe
     assert pops.shape == (143, 5) and np.all(pops.sum(1) == 32 ** 3)
     frac = 1.0 - pops[:, 0] / 32 ** 3
     assert np.all(frac[:80] < 2e-3)                                              # everybody on rung 0 while the field is smooth
-    assert frac[-1] == pytest.approx(frac_ref[-1], rel=0.5) and frac[120] == pytest.approx(frac_ref[120], rel=0.6)
-    assert np.all(np.diff(frac[96:128:8]) > 0)                                   # and the population of the higher rungs grows as structure forms
+    # the logged curve (mean of 300 runs; one realisation here scatters by ~15 %): 0.8 % at step 112, 2.5 % at 120, 5.2 % at 128, 6.1 % at 136, 5.7 % at 141
+    for k in (112, 120, 128, 136, 141):
+        assert frac[k] == pytest.approx(frac_ref[k], rel=0.45), (k, frac[k], frac_ref[k])
+    assert np.mean(frac[112:142] / frac_ref[112:142]) == pytest.approx(1.0, abs=0.3)
+    # the split over the rungs at step 138 (…/params_id0200_*.log:6500: 30644, 1418, 695, 11)
+    assert pops[138, 1] == pytest.approx(1418, rel=0.3) and pops[138, 2] == pytest.approx(695, rel=0.55) and pops[138, 3] < 60
+    assert np.all(np.diff(frac[96:128:8]) > 0)                                   # the higher rungs fill as structure forms
     # same base steps without the hierarchy vs with it vs the step-converged run: the hierarchy recovers the small-scale power
     p_0, _ = cosmo.run_pp(pos, vel, m, 500.0, c, 0.02, 1.0, dtype=np.float32, gravity="p3m", ngrid=32, schedule="concept")
     p_c, _ = cosmo.run_pp(pos, vel, m, 500.0, c, 0.02, 1.0, nsteps=600, dtype=np.float32, gravity="p3m", ngrid=32)
