@@ -2,7 +2,7 @@
 32^3 particles, 500 Mpc, 'p3m' on a 32^3 interlaced mesh, a = 0.02 -> 1) re-run here job by job with the SAME A_s values (own
 seeds), against the ensemble of the reference's 100 snapshots: binned P(k) (tests/golden/concept/p3m_farm_test100_pk.txt) and the
 moments of the CIC-deposited, deconvolved density contrast the CNN is fed (p3m_farm_ensemble_moments.txt). No amplitude scaling
-is applied to either side: the non-linear spectrum is not proportional to A_s. usage: p3m_farm_test100.py [nsteps|concept] [lpt] [pm|p3m|pp]"""
+is applied to either side: the non-linear spectrum is not proportional to A_s. usage: p3m_farm_test100.py [nsteps|concept|rungs] [lpt] [pm|p3m|pp]"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,8 @@ from bachelor_thesis_n_body_amd import cosmo, field
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden", "concept"))
 from make_p3m_momentum import momentum_stats          # the estimator the momentum fixture was made with (NumPy oracle deposit)
 
-schedule = "concept" if (len(sys.argv) > 1 and sys.argv[1] == "concept") else None      # the reference farm's own logged base steps
+schedule = "concept" if (len(sys.argv) > 1 and sys.argv[1] in ("concept", "rungs")) else None      # the reference farm's own logged base steps
+rungs = len(sys.argv) > 1 and sys.argv[1] == "rungs"                                                 # ... with the rung hierarchy for the short-range force
 nsteps = 143 if schedule else (int(sys.argv[1]) if len(sys.argv) > 1 else 400)
 lpt = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 grav = sys.argv[3] if len(sys.argv) > 3 else "p3m"
@@ -32,7 +33,10 @@ t0 = time.perf_counter()
 for i, A in enumerate(a_s):
     t = tab.copy(); t[:, 1] *= A / 2.105e-9                      # the table is CLASS' linear spectrum for A_s = 2.105e-9 (NN.param:92)
     pos, vel = cosmo.zeldovich_ics(t, n_side, L, c, 0.02, 300 + i, 9000 + i, lpt=lpt)
-    pos, vel = cosmo.run_pp(pos, vel, c.particle_mass(L, n_side ** 3), L, c, 0.02, 1.0, nsteps, dtype=np.float32, gravity=grav, ngrid=32, schedule=schedule)
+    if rungs:
+        pos, vel = cosmo.run_rungs(pos, vel, c.particle_mass(L, n_side ** 3), L, c, 0.02, 1.0, ngrid=32)
+    else:
+        pos, vel = cosmo.run_pp(pos, vel, c.particle_mass(L, n_side ** 3), L, c, 0.02, 1.0, nsteps, dtype=np.float32, gravity=grav, ngrid=32, schedule=schedule)
     k, p = cosmo.power_modes(pos, L, n_side, interlace=True)
     which = np.digitize(k, edges) - 1
     ok = (which >= 0) & (which < len(edges) - 1)
@@ -47,7 +51,7 @@ rows, mom = np.array(rows), np.array(mom)
 n = len(a_s)
 mean, err = rows.mean(0), rows.std(0, ddof=1) / np.sqrt(n)
 ref_err = ens[:, 5] / np.sqrt(ens[:, 6])
-steps_txt = "CONCEPT's logged 143-step schedule" if schedule else f"{nsteps} steps uniform in ln a"
+steps_txt = "CONCEPT's logged 143-step schedule + rung hierarchy (eta = 0.018)" if rungs else "CONCEPT's logged 143-step schedule" if schedule else f"{nsteps} steps uniform in ln a"
 print(f"# 100 jobs with the reference's A_s values, {lpt}LPT, {steps_txt}, gravity {grav!r}: {wall:.1f} s ({wall/n:.2f} s per job incl. ICs, P(k), delta field)")
 print("#  mean_k    modes   P reference     +-        P here          +-      ratio    +-")
 ratio, rerr = mean / ens[:, 4], np.hypot(err / ens[:, 4], mean * ref_err / ens[:, 4] ** 2)

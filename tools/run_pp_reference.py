@@ -3,14 +3,15 @@ H0 = 67.36, omega_b = 0.02237, omega_cdm = 0.12 (PPPMP3M/pppmp3mplotter.py:11-22
 took CONCEPT 2 days 23:27:37 on the author's desktop. Initial conditions: Zel'dovich from the `P linear` column of the
 reference's own table (tests/golden/concept/PP_powerspec_a=1.00); output: P(k) at a = 1 in CONCEPT's 16 bins next to the
 reference's `P` column, the realisation-corrected column next to the reference's `P corrected`, and sigma_8 of both next to the values
-in the table's header. Prints a text table + one JSON summary line. usage: run_pp_reference.py [nsteps|concept] [n_side] [seed] [f32|f64] [lpt] [pp|pm|p3m]"""
+in the table's header. Prints a text table + one JSON summary line. usage: run_pp_reference.py [nsteps|concept|rungs] [n_side] [seed] [f32|f64] [lpt] [pp|pm|p3m]"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bachelor_thesis_n_body_amd import cosmo, field
 
-schedule = "concept" if (len(sys.argv) > 1 and sys.argv[1] == "concept") else None      # CONCEPT's own base steps (cosmo.load_concept_schedule)
+schedule = "concept" if (len(sys.argv) > 1 and sys.argv[1] in ("concept", "rungs")) else None      # CONCEPT's own base steps (cosmo.load_concept_schedule)
+rungs = len(sys.argv) > 1 and sys.argv[1] == "rungs"                                                 # ... with the rung hierarchy (cosmo.run_rungs; p3m only)
 nsteps = 143 if schedule else (int(sys.argv[1]) if len(sys.argv) > 1 else 400)
 n_side = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
@@ -28,7 +29,10 @@ c = cosmo.Cosmology.from_h_omegas(0.6736, 0.02237, 0.12)
 t0 = time.perf_counter()
 pos, vel, noise = cosmo.zeldovich_ics(tab, n_side, L, c, a_begin, seed, seed + 1000, lpt=lpt, return_noise_power=True)
 mass = c.particle_mass(L, n_side ** 3)
-pos, vel = cosmo.run_pp(pos, vel, mass, L, c, a_begin, 1.0, nsteps, dtype=dtype, gravity=grav, ngrid=n_side, schedule=schedule)
+if rungs:
+    pos, vel, pops = cosmo.run_rungs(pos, vel, mass, L, c, a_begin, 1.0, dtype=dtype, ngrid=n_side, return_populations=True)
+else:
+    pos, vel = cosmo.run_pp(pos, vel, mass, L, c, a_begin, 1.0, nsteps, dtype=dtype, gravity=grav, ngrid=n_side, schedule=schedule)
 t_run = time.perf_counter() - t0
 kmag, pk = cosmo.power_modes(pos, L, n_side, interlace=True)     # CONCEPT's estimator settings: CIC, deconvolved, interlaced
 kv = 2 * np.pi * np.fft.fftfreq(n_side, d=L / n_side)
@@ -37,7 +41,7 @@ r2 = np.asarray(noise, np.float64)[np.sqrt(kx ** 2 + ky ** 2 + kz ** 2) > 0]    
 plin_modes = np.exp(np.interp(np.log(kmag), np.log(tab[:, 0]), np.log(tab[:, 1])))
 counts = modes if n_side == 64 else modes[: max(2, len(modes) // 2)]
 k_b, p_b, pc_b = cosmo.rebin_corrected_like_concept(kmag, pk, plin_modes, r2, counts)
-steps_txt = "CONCEPT's logged schedule (143 base steps, constant in cosmic time over 8 steps)" if schedule else f"{nsteps} steps uniform in ln a"
+steps_txt = ("CONCEPT's logged schedule (143 base steps) + rung hierarchy for the short-range force, final populations " + str(pops[-2].tolist())) if rungs else "CONCEPT's logged schedule (143 base steps, constant in cosmic time over 8 steps)" if schedule else f"{nsteps} steps uniform in ln a"
 print(f"# gravity {grav!r}; {lpt}LPT ICs; {n_side}^3 particles, {steps_txt}, {np.dtype(dtype).name} forces, wall {t_run:.1f} s (CONCEPT pp: 257257 s)")
 print("#  k_ref      k_here     modes   P_ref        P_here       ratio  | Pcorr_ref    Pcorr_here   ratio  | P_ref/P_lin  P_here/P_lin")
 for i in range(len(k_b)):
