@@ -101,11 +101,19 @@ def _run_cosmological(args, p, s) -> int:
     total = np.log(outs[-1] / a0)
     for a1 in outs:
         k = max(1, round(nsteps * np.log(a1 / a0) / total))
-        pos, vel = cosmo.run_pp(pos, vel, mass, L, c, a0, a1, nsteps=k, eps=args.eps, gravity=s["gravity"],
-                                dtype=np.float32 if args.dtype == "f32" else np.float64,
-                                ngrid=s["mesh"]["gridsize"], interlace=s["mesh"]["interlace"],
-                                scale_cells=s["mesh"]["scale"], range_scales=s["mesh"]["range"],
-                                schedule="concept" if args.schedule == "concept" else None)
+        if args.schedule == "rungs":
+            if s["gravity"] != "p3m":
+                print("concept: --schedule rungs needs select_forces gravity 'p3m' (the rungs belong to its short-range force)", file=sys.stderr)
+                return 2
+            pos, vel = cosmo.run_rungs(pos, vel, mass, L, c, a0, a1, eps=args.eps, dtype=np.float32 if args.dtype == "f32" else np.float64,
+                                       ngrid=s["mesh"]["gridsize"], interlace=s["mesh"]["interlace"], scale_cells=s["mesh"]["scale"],
+                                       range_scales=s["mesh"]["range"])
+        else:
+            pos, vel = cosmo.run_pp(pos, vel, mass, L, c, a0, a1, nsteps=k, eps=args.eps, gravity=s["gravity"],
+                                    dtype=np.float32 if args.dtype == "f32" else np.float64,
+                                    ngrid=s["mesh"]["gridsize"], interlace=s["mesh"]["interlace"],
+                                    scale_cells=s["mesh"]["scale"], range_scales=s["mesh"]["range"],
+                                    schedule="concept" if args.schedule == "concept" else None)
         if a1 in snap_t:
             snapshot.write_snapshot(str(out / f"snapshot_a={a1:.2f}.hdf5"), pos, vel * mass, L, mass=mass,
                                     extra_attrs={"a": float(a1), "H0": float(p["H0"]), "Ωb": float(p["Ωb"]), "Ωcdm": float(p["Ωcdm"])})
@@ -136,9 +144,10 @@ def main(argv=None) -> int:
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f64")
     ap.add_argument("--solver", choices=["direct", "tree"], default="direct")
     ap.add_argument("--theta", type=float, default=0.5)
-    ap.add_argument("--schedule", choices=["lna", "concept"], default="lna",
+    ap.add_argument("--schedule", choices=["lna", "concept", "rungs"], default="lna",
                     help="time steps of a --cosmological run: 'lna' = --steps steps uniform in ln a (default); 'concept' = CONCEPT's own base steps "
-                         "as the reference's run logs record them (143 from a = 0.02 to 1; cosmo.load_concept_schedule)")
+                         "as the reference's run logs record them (143 from a = 0.02 to 1; cosmo.load_concept_schedule); 'rungs' = those base steps with a rung "
+                         "hierarchy for the short-range force ('gravity': 'p3m' only; cosmo.run_rungs — CONCEPT's time-loop structure)")
     ap.add_argument("--cosmological", action="store_true",
                     help="comoving integration from a_begin to the largest output time in a periodic box (Ewald forces, fp64): "
                          "the physics of a CONCEPT `pp` run; --steps counts steps uniform in ln a (default 400)")
