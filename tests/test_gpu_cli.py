@@ -154,3 +154,21 @@ def test_cli_concept_schedule_with_an_intermediate_output(tmp_path):
     moved = wrap(out["one"] - q).mean()                                  # mean displacement from the lattice at a = 1
     assert wrap(out["one"] - out["two"]).max() < 2e-2 * moved            # one extra step boundary at a = 0.5
     assert wrap(out["one"] - out["lna"]).mean() < 2e-2 * moved           # 143 CONCEPT steps vs 300 uniform ones: same trajectory
+
+
+def test_cli_rung_hierarchy_needs_p3m_and_runs(tmp_path):
+    """`--schedule rungs`: CONCEPT's base steps + the rung hierarchy for the p3m short-range force (cosmo.run_rungs); refused for other solvers."""
+    k = np.logspace(-3, 1, 200)
+    np.savetxt(tmp_path / "pk.txt", np.column_stack([k, 2.0e4 * (k / 0.02) / (1 + (k / 0.02) ** 2) ** 1.6]))
+    d = tmp_path / "pp"; d.mkdir()
+    assert concept.main(["-p", str(_write(d, gravity="pp")), "--cosmological", "--pk-table", str(tmp_path / "pk.txt"), "--schedule", "rungs"]) == 2
+    out = {}
+    for name, extra in (("rungs", ["--schedule", "rungs"]), ("lna", ["--steps", "300"])):
+        d = tmp_path / name; d.mkdir()
+        f = _write(d, gravity="p3m")
+        assert concept.main(["-p", str(f), "--cosmological", "--dtype", "f32", "--pk-table", str(tmp_path / "pk.txt")] + extra) == 0
+        out[name] = sn.read_positions(str(sorted(d.rglob("snapshot_a=1.00.hdf5"))[0]))
+    wrap = lambda x: np.abs((x + 250.0) % 500.0 - 250.0)
+    g = np.linspace(0, 500.0, 8, endpoint=False)
+    q = np.array(np.meshgrid(g, g, g, indexing="ij")).reshape(3, -1).T
+    assert wrap(out["rungs"] - out["lna"]).mean() < 3e-2 * wrap(out["lna"] - q).mean()
