@@ -166,7 +166,9 @@ def test_cli_rung_hierarchy_needs_p3m_and_runs(tmp_path):
     for name, extra in (("rungs", ["--schedule", "rungs"]), ("lna", ["--steps", "300"])):
         d = tmp_path / name; d.mkdir()
         f = _write(d, gravity="p3m")
-        assert concept.main(["-p", str(f), "--cosmological", "--dtype", "f32", "--pk-table", str(tmp_path / "pk.txt")] + extra) == 0
+        mesh = ["-c", "potential_options = {'gridsize': {'particles': {'gravity': {'pm': 'cbrt(N)', 'p3m': '3*cbrt(N)'}}}, "
+                      "'interlace': {'gravity': {'pm': (True, True), 'p3m': (True, True)}}}"]
+        assert concept.main(["-p", str(f), "--cosmological", "--dtype", "f32", "--pk-table", str(tmp_path / "pk.txt")] + mesh + extra) == 0
         out[name] = sn.read_positions(str(sorted(d.rglob("snapshot_a=1.00.hdf5"))[0]))
     wrap = lambda x: np.abs((x + 250.0) % 500.0 - 250.0)
     g = np.linspace(0, 500.0, 8, endpoint=False)
