@@ -7,7 +7,7 @@ Each base step of the main loop prints (e.g. params_id0200_....log:49-55, 89-96)
     Time step 17 / Scale factor: 0.02512 / Cosmic time: 0.06750 Gyr / Step size: 0.006071 Gyr / Rung population: matter: 32760, 8
 Output (committed beside this script, the script itself needs /root/reference and is not run by the tests):
     concept_step_schedule.txt  — columns: step, a (scale factor at the START of the step), cosmic time t [Gyr], step size dt [Gyr],
-                                 then over all logs found: min / max of a at that step index, and the mean fraction of particles above rung 0
+                                 then over all logs found: min / max of a at that step index, the mean fraction of particles above rung 0, the number of logs, and the mean populations of rungs 0..4
     concept_step_schedule_runs.txt — per log: id, A_s, number of base steps, a at the last step, largest rung ever populated
 Usage: python make_step_schedule.py [/root/reference]"""
 import re
@@ -50,10 +50,15 @@ def main():
     for i, (step, a, t, dt, rungs) in enumerate(base):
         a_all = np.array([r[2][i][1] for r in runs if len(r[2]) > i])
         hi = np.array([1.0 - r[2][i][4][0] / sum(r[2][i][4]) for r in runs if len(r[2]) > i])
-        rows.append([step, a, t, dt, a_all.min(), a_all.max(), hi.mean(), len(a_all)])
-    np.savetxt(here / "concept_step_schedule.txt", np.array(rows), fmt=["%d", "%.5f", "%.5f", "%.6f", "%.5f", "%.5f", "%.5f", "%d"],
+        pops = np.zeros(5)
+        for r in runs:
+            if len(r[2]) > i:
+                for l, v in enumerate(r[2][i][4][:5]):
+                    pops[l] += v
+        rows.append([step, a, t, dt, a_all.min(), a_all.max(), hi.mean(), len(a_all)] + list(pops / len(a_all)))
+    np.savetxt(here / "concept_step_schedule.txt", np.array(rows), fmt=["%d", "%.5f", "%.5f", "%.6f", "%.5f", "%.5f", "%.5f", "%d"] + ["%.2f"] * 5,
                header="CONCEPT base time steps of job id0200 (TheFeedingPipeline/Datafolder4/Test_Data_concept/id0200_*/params_id0200_*.log), a = 0.02 -> 1, 32^3 p3m\n"
-                      "step  a_start  t[Gyr]  dt[Gyr]  min_a_over_runs  max_a_over_runs  mean_fraction_above_rung0  runs_with_this_step\n"
+                      "step  a_start  t[Gyr]  dt[Gyr]  min_a_over_runs  max_a_over_runs  mean_fraction_above_rung0  runs_with_this_step  mean populations of rungs 0..4 (of 32768)\n"
                       f"{len(runs)} logs parsed; longest run {nmax} steps")
     with open(here / "concept_step_schedule_runs.txt", "w") as f:
         f.write("# folder id A_s base_steps a_last_step max_rung\n")

@@ -50,8 +50,10 @@ def test_rung_populations_follow_the_reference_logs_and_restore_small_scale_powe
     for k in (112, 120, 128, 136, 141):
         assert frac[k] == pytest.approx(frac_ref[k], rel=0.45), (k, frac[k], frac_ref[k])
     assert np.mean(frac[112:142] / frac_ref[112:142]) == pytest.approx(1.0, abs=0.3)
-    # the split over the rungs at step 138 (…/params_id0200_*.log:6500: 30644, 1418, 695, 11)
-    assert pops[138, 1] == pytest.approx(1418, rel=0.3) and pops[138, 2] == pytest.approx(695, rel=0.55) and pops[138, 3] < 60
+    # the split over the rungs late in the run: mean populations of the 300 logs (columns 9-13 of the fixture; e.g. step 138: 30 840 / 1 300 / 610 / 18)
+    mean_pop = sched[130:142, 8:13].mean(0)
+    ours = pops[130:142].mean(0)
+    assert ours[1] == pytest.approx(mean_pop[1], rel=0.3) and ours[2] == pytest.approx(mean_pop[2], rel=0.55) and ours[3] < 5 * max(mean_pop[3], 10), (ours, mean_pop)
     assert np.all(np.diff(frac[96:128:8]) > 0)                                   # the higher rungs fill as structure forms
     # same base steps without the hierarchy vs with it vs the step-converged run: the hierarchy recovers the small-scale power
     p_0, _ = cosmo.run_pp(pos, vel, m, 500.0, c, 0.02, 1.0, dtype=np.float32, gravity="p3m", ngrid=32, schedule="concept")
