@@ -527,7 +527,14 @@ int nb_rung_step(nb_ctx* c, int levels, const double* kc, const double* dc, doub
       rc = force(1); if (rc) return rc;
       NB_HIP(c, hipMemcpyAsync(c->acc_lr, ax, 3 * b, hipMemcpyDeviceToDevice, c->stream));
     }
-    rc = force(2); if (rc) return rc;
+    // after this drift only the rungs with a step boundary at sub + 1 need their pair force: l >= top - (trailing zeros of sub + 1); all at the end
+    int tz = 0;
+    for (int j = sub + 1; sub + 1 < S && !(j & 1); j >>= 1) ++tz;
+    c->sr_rung = sub + 1 < S ? c->rung : nullptr;
+    c->sr_min_rung = top - tz > 0 ? top - tz : 0;
+    rc = force(2);
+    c->sr_rung = nullptr; c->sr_min_rung = 0;
+    if (rc) return rc;
     rc = nb_launch_rung_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->rung, c->n, 1, sub, S, top, dkc); if (rc) return rc;
   }
   rc = nb_launch_kick(c, c->dtype, vx, vy, vz, c->acc_lr, (char*)c->acc_lr + b, (char*)c->acc_lr + 2 * b, c->n, k2[2 * S] - k2[S]); if (rc) return rc;

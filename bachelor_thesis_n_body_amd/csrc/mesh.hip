@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(64 * SRW)
 short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ keys_s, const int* __restrict__ cell_start,
                    const int* __restrict__ chunk_off, int nrows, int nc, T L, T alpha, T rcut2, T eps2, double G,
                    const uint32_t* __restrict__ idx_s, const float* __restrict__ table, T* __restrict__ ax, T* __restrict__ ay,
-                   T* __restrict__ az, double* __restrict__ part, int64_t n) {
+                   T* __restrict__ az, double* __restrict__ part, int64_t n, const unsigned char* __restrict__ rung, int min_rung) {
   // gridDim.y = 1: the wave walks all 9 neighbouring rows and adds its result to ax/ay/az. gridDim.y = 9 * zparts (few chunks: the launch
   // could not fill the chip, and a lone wave per SIMD crawls through ~7000 sources at one instruction every few cycles — the walk is a chain
   // of dependent LDS round trips): wave (chunk, blockIdx.y) walks ONE neighbouring row and, of its cells, every zparts-th one, and stores its
@@ -435,6 +435,12 @@ short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ k
   V4 me[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) me[k] = sorted[min(i_first + k * 64 + lane, i_last)];
+  if (rung) {     // rung hierarchy: only particles on rung >= min_rung need their force now; a chunk without any is skipped (its sinks keep 0)
+    bool act = false;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) { const int i = i_first + k * 64 + lane; if (i <= i_last) act |= rung[idx_s[i]] >= min_rung; }
+    if (__builtin_amdgcn_ballot_w64(act) == 0) return;
+  }
   const T c2 = (T)2 * alpha * (T)0.5641895835477563, a2l = 0;
   const float tscale = TABLE ? (float)TABN / (float)rcut2 : 0.f;
   double tx[KS], ty[KS], tz[KS];
@@ -647,7 +653,7 @@ int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z,
   const dim3 sr_grid((unsigned)((max_chunks + SRW - 1) / SRW), (unsigned)ny);
   const bool soft = eps2 > 0.0 && (sizeof(T) == 8 || (float)eps2 > 1e-30f), uni = c->uniform_mass;
 #define NB_SR2(K, SF, UN) short_range_kernel<T, V4, K, SF, UN><<<sr_grid, 64 * SRW, 0, st>>>((const V4*)s.sorted, s.keys_s, \
-    s.cell_start, s.chunk_off, nrows, nc, (T)L, (T)alpha, (T)(rcut * rcut), (T)eps2, G, s.idx_s, s.table, ax, ay, az, part, n)
+    s.cell_start, s.chunk_off, nrows, nc, (T)L, (T)alpha, (T)(rcut * rcut), (T)eps2, G, s.idx_s, s.table, ax, ay, az, part, n, c->sr_rung, c->sr_min_rung)
 #define NB_SR(K) do { if (soft && uni) NB_SR2(K, true, true); else if (soft) NB_SR2(K, true, false); else if (uni) NB_SR2(K, false, true); \
                       else NB_SR2(K, false, false); } while (0)
   if (ks == 1) NB_SR(1); else if (ks == 2) NB_SR(2); else NB_SR(4);
