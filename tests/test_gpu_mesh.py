@@ -286,6 +286,14 @@ def test_contexts_release_all_device_memory():
                 e.accel(0.1, fetch=False)
                 if setup is None:
                     e.step_with_energy(0.01, 2, 0.1)            # direct solver: the phi / energy-log buffers too
+        with nb.Engine(n, np.float32, devices=[0, 0, 0]) as e:  # multi-device context: shards, receive buffers, copy streams, events
+            e.set_state(s)
+            e.step_with_energy(0.01, 2, 0.1)
+        with nb.Engine(n, np.float32) as e:                     # graph-replayed run + rung hierarchy: factor tables, graphs, rung arrays
+            e.set_mesh("p3m", L, 32)
+            e.set_state(s)
+            e.kdk_run(np.full(9, 0.01), np.full(9, 0.01), np.full(9, 0.01), 0.1)
+            e.rung_step(3, np.linspace(0, 0.02, 9), np.linspace(0, 0.02, 9), 0.02, 1e-4, 0.1)
     cycle()                                   # first use: library-level caches (hipFFT kernels, rocPRIM) are allocated once
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
