@@ -63,3 +63,37 @@ def test_rung_populations_follow_the_reference_logs_and_restore_small_scale_powe
     hi = k > 0.15
     r0, rr = pk_0[hi].mean() / pk_c[hi].mean(), pk_r[hi].mean() / pk_c[hi].mean()
     assert r0 < 0.985 and abs(rr - 1.0) < abs(r0 - 1.0) * 0.6, (r0, rr)
+
+
+def test_rung_step_argument_checks_and_interplay_with_plain_steps():
+    import bachelor_thesis_n_body_amd as nb
+    rng = np.random.default_rng(0)
+    n, L = 3000, 30.0
+    s = nb.State(rng.uniform(0, L, (n, 3)).astype(np.float32), rng.normal(size=(n, 3)).astype(np.float32) * 0.1, np.full(n, 1.0, np.float32))
+    kc, dc = np.linspace(0, 0.02, 5), np.linspace(0, 0.02, 5)
+    with nb.Engine(n, np.float32) as e:
+        e.set_state(s)
+        with pytest.raises(RuntimeError, match="P3M"):
+            e.rung_step(2, kc, dc, 0.02, 1e-4, 0.1)                 # direct solver: no short/long-range split
+        e.set_mesh("p3m", L, 32)
+        with pytest.raises(ValueError):
+            e.rung_step(3, kc, dc, 0.02, 1e-4, 0.1)                 # tables of the wrong length for 3 levels
+        pops = e.rung_step(2, kc, dc, 0.02, 1e-4, 0.1)
+        assert sum(pops) == n
+        a_after = e.accel(0.1)                                      # a plain force evaluation afterwards is the TOTAL force again
+        st = e.get_state()
+    with nb.Engine(n, np.float32) as e:
+        e.set_mesh("p3m", L, 32)
+        e.set_state(st)
+        np.testing.assert_allclose(e.accel(0.1), a_after, rtol=0, atol=1e-5 * np.abs(a_after).max())
+    # a huge criterion puts everybody on rung 0: the step is then one KDK step with these factors
+    with nb.Engine(n, np.float32) as e:
+        e.set_mesh("p3m", L, 32); e.set_state(s)
+        assert e.rung_step(3, np.linspace(0, 0.02, 9), np.linspace(0, 0.02, 9), 0.02, 1e30, 0.1) == [n, 0, 0]
+        r = e.get_state()
+    with nb.Engine(n, np.float32) as e:
+        e.set_mesh("p3m", L, 32); e.set_state(s)
+        e.kdk_step(0.01, 0.02, 0.01, 0.1)
+        k = e.get_state()
+    d = np.abs(r.pos - k.pos); d = np.minimum(d, L - d)
+    assert d.max() < 1e-4 and np.abs(r.vel - k.vel).max() < 1e-4 * np.abs(k.vel).max()
