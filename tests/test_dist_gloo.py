@@ -35,7 +35,17 @@ def _worker(rank, world, port, n, mode, out_dir):
         eng = nb.ShardedEngine(n, np.float64, device="cpu", kernels=OracleKernels(), mode=mode)
         assert sum(eng.counts) == n and eng.n_loc == eng.counts[rank]
         eng.set_state(s)
+        from bachelor_thesis_n_body_amd.dist import HopProbe
+        probe = HopProbe(torch, torch.device("cpu"))       # per-hop exchange timing (bench.py's `ring` block) on the host clock
+        eng.hop_probe = probe
+        probe.enabled = mode == "ring"
         eng.accel(eps)
+        probe.enabled = False
+        if mode == "ring":
+            ps = probe.summary()
+            assert ps["hops_timed"] == world - 1 and ps["comm_ms"] >= 0.0
+        else:
+            assert probe.summary() is None
         acc0 = eng.gather_state().acc
         k0, u0 = eng.energy(eps)
         eng.step(dt, 3, eps)
