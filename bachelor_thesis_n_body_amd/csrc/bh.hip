@@ -267,6 +267,12 @@ constexpr int LSTACK = 12288;      // entries per wave-private stack (<= 128 nod
 // The list walk (see the header). Stack entries live in global memory (L2-resident, wave-private); entries written by
 // one lane are read by another lane of the same wave in a later pass, so every store is drained (s_waitcnt vmcnt(0))
 // before the next pass loads, and the loads bypass the vector L1.
+#ifndef NB_BH_UMAC
+#define NB_BH_UMAC 4
+#endif
+#ifndef NB_BH_USWEEP
+#define NB_BH_USWEEP 8
+#endif
 #ifndef NB_BH_WPE
 #define NB_BH_WPE 6                // waves per SIMD the list walk is compiled for (79 VGPRs; N = 16M: 4: 43.5 ms, 5: 42.2, 6: 41.7, 7: 41.9)
 #endif
@@ -349,7 +355,7 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
       if (v >= 0) { c = com[v]; r = rec[v]; }
       // squared distance from this lane's node to the nearest acceptance volume of the group (wave-uniform trip count)
       float d2 = 3.4e38f;
-#pragma unroll 4
+#pragma unroll NB_BH_UMAC
       for (int e = 0; e < nvol; ++e) {
         const float4 lo = vlo[e], hi = vhi[e];                        // LDS broadcasts
         const float ex = fmaxf(fmaxf(lo.x - c.x, c.x - hi.x), 0.f), ey = fmaxf(fmaxf(lo.y - c.y, c.y - hi.y), 0.f),
@@ -385,7 +391,7 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
       }
       NB_WAVE_SYNC();
       // ---- monopoles of this pass
-#pragma unroll 4
+#pragma unroll NB_BH_USWEEP
       for (int e = 0; e < n_acc; ++e) {
         const float4 q = mono[e];                                                    // LDS broadcast (ds_read_b128)
         const float qm = q.w;
@@ -406,7 +412,7 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
         }
         NB_WAVE_SYNC();
         const int m = total_leaf - base < 64 ? total_leaf - base : 64;
-#pragma unroll 4
+#pragma unroll NB_BH_USWEEP
         for (int e = 0; e < m; ++e) {
           const float4 q = tile[e];
           const float qm = q.w;
