@@ -385,3 +385,30 @@ def test_config3_n4M_fp64_full_size(coracle):
     assert abs(2 * k0 / abs(u0) - 1) < 0.02 and abs(e0 + 0.25) < 0.01
     drift = np.abs((K + U) - e0).max() / abs(e0)
     assert drift < 1e-7, f"max |dE/E| over 4 steps = {drift:.3e}"
+
+
+# ------------------------------------------------------------------ degenerate sizes
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_single_particle_and_two_coincident_particles(dtype):
+    """N = 1: no force, free drift, zero potential. N = 2 at the same position with eps = 0: the coincident pair contributes nothing (GUARD variant)."""
+    s = nb.State(np.array([[0.1, 0.2, 0.3]], dtype), np.array([[1.0, 0.0, -1.0]], dtype), np.array([2.0], dtype))
+    with nb.Engine(1, dtype) as e:
+        e.set_state(s)
+        assert np.all(e.accel(0.01) == 0.0)
+        e.step(0.5, 2, 0.01)
+        st = e.get_state()
+        k, u = e.energy(0.01)
+    np.testing.assert_allclose(st.pos, [[1.1, 0.2, -0.7]], rtol=2e-7)
+    assert u == 0.0 and k == pytest.approx(2.0, rel=1e-6)
+    s2 = nb.State(np.zeros((2, 3), dtype), np.zeros((2, 3), dtype), np.ones(2, dtype))
+    with nb.Engine(2, dtype) as e:
+        e.set_state(s2)
+        assert np.all(e.accel(0.0) == 0.0)
+        k, u = e.energy(0.0)
+        assert u == 0.0
+    with nb.Engine(3, dtype, devices=[0, 0, 0]) as e:           # one particle per device
+        s3 = nb.plummer_sphere(3, 1, dtype)
+        e.set_state(s3)
+        a = e.accel(0.05)
+    ref = ora.compute_forces(s3.pos.astype(np.float64), s3.mass.astype(np.float64), 0.05)
+    assert rel_err(a, ref).max() < TOL[dtype]
