@@ -20,7 +20,8 @@
  *  - a_i = G * sum_j m_j (r_j - r_i) / (|r_j - r_i|^2 + eps^2)^{3/2}   (Plummer softening;
  *    pairs with |r_j - r_i|^2 + eps^2 == 0 contribute nothing), SURVEY.md §7.2.
  *  - step = kick-drift-kick leapfrog, one force evaluation per step, acceleration cached.
- *  - a context is bound to one GPU and is NOT thread-safe; one context per host thread.
+ *  - a context is NOT thread-safe (one context per host thread); nb_create binds it to one GPU, nb_create_multi spreads its particles
+ *    over several GPUs of the node (sink decomposition, peer pulls of the source blocks).
  *  - "_dev" functions take DEVICE pointers (e.g. torch tensors' data_ptr()) and enqueue on the
  *    context's stream without synchronising; the others take HOST pointers and copy.
  */
