@@ -360,6 +360,8 @@ def main():
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "flop_per_interaction": FLOP_PER_INTERACTION,
                          "interactions_per_launch": k_inter, "avg_launch_ms": k_ms, "launches_timed": k_count,
+                         # rank 0's accel launches per step, back to back: what ms_per_step would be with a free exchange and free O(N) kernels
+                         "kernel_ms_per_step": k_ms * k_count / max(1, args.steps),
                          "traffic": None,
                          "traffic_source": "NOT measured in this run: HBM bytes per launch from the rocprofv3 --pmc passes of this same command committed as profiles/r02_bench_n1_uniform_rocprofv3_summary.txt (FETCH_SIZE x2 + WRITE_SIZE; 0.4 GB = the fp64 slab of the 8-way source split); algorithmic bytes = 28*N"},
         }
