@@ -203,7 +203,12 @@ class HopProbe:
 class ShardedEngine:
     """Sink-decomposed engine of one rank. All ranks must make the same sequence of calls."""
 
-    def __init__(self, n_total: int, dtype=np.float32, device=None, group=None, kernels=None, mode: str = "ring"):
+    def __init__(self, n_total: int, dtype=np.float32, device=None, group=None, kernels=None, mode: str = "ring", virtual_world: int = 0):
+        """virtual_world = P > 1 (rehearsal on ONE GPU with the real transport): the process group has a single rank, which plays rank 0 of a
+        P-rank ring — it owns the first of P sink ranges, holds the other ranks' source blocks locally, and at every hop sends the block its
+        predecessor would have sent TO ITSELF through the communicator (RCCL supports a send/receive pair on one rank). Everything the
+        RCCL path relies on is then exercised for real — batch_isend_irecv posted before the kernel, the communicator stream's ordering against the
+        compute stream, wait(), receive-buffer reuse — except the xGMI link. Only accel() / local_acc() make sense in this mode."""
         import torch
         import torch.distributed as dist
 
@@ -211,6 +216,11 @@ class ShardedEngine:
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.virtual = None
+        if virtual_world and virtual_world > 1:
+            if not dist.is_initialized() or self.world != 1 or mode != "ring":
+                raise ValueError("virtual_world needs an initialised single-rank process group and mode='ring'")
+            self.world = int(virtual_world)
         self.n_total = int(n_total)
         self.counts, self.offsets = partition(self.n_total, self.world)
         self.n_loc, self.off = self.counts[self.rank], self.offsets[self.rank]
@@ -234,6 +244,8 @@ class ShardedEngine:
         self.vel = z(3, self.n_max)
         self.acc = z(3, self.n_max)
         self.ring = [z(4, self.n_max), z(4, self.n_max)] if self.world > 1 else []
+        if virtual_world and virtual_world > 1:
+            self.virtual = z(self.world, 4, self.n_max)      # the source blocks of the other (virtual) ranks
         self.gathered = z(self.world, 4, self.n_max) if (self.world > 1 and mode == "allgather") else None
         self.scal = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.phi = None                # per-sink potential of the fused force+potential kernels (step_with_energy)
@@ -259,6 +271,13 @@ class ShardedEngine:
         self.uniform_mass = bool(m_all.size > 0 and np.all(m_all == m_all.flat[0]))
         self.pm.copy_(t.from_numpy(pm))
         self.vel.copy_(t.from_numpy(vel))
+        if self.virtual is not None:
+            allpm = np.zeros((self.world, 4, self.n_max), self.np_dtype)
+            for o in range(self.world):
+                so = slice(self.offsets[o], self.offsets[o] + self.counts[o])
+                allpm[o, :3, : self.counts[o]] = np.asarray(state.pos)[so].T
+                allpm[o, 3, : self.counts[o]] = np.asarray(state.mass)[so]
+            self.virtual.copy_(t.from_numpy(allpm))
         self._acc_key = None
 
     def gather_state(self) -> State:
@@ -302,6 +321,8 @@ class ShardedEngine:
                 fn(self.gathered[o], o, False)
             return
         nxt_rank, prv_rank = (r + 1) % P, (r - 1) % P
+        if self.virtual is not None:
+            nxt_rank = prv_rank = dist.get_rank(self.group)          # the one real rank sends to itself what its predecessor would send
         if self.group is not None:
             nxt_rank, prv_rank = dist.get_global_rank(self.group, nxt_rank), dist.get_global_rank(self.group, prv_rank)
         cur = self.pm
@@ -312,7 +333,8 @@ class ShardedEngine:
                 if self.hop_probe is not None and self.hop_probe.enabled:
                     self.hop_probe.posting()
                 recv_buf = self.ring[h & 1]
-                ops = [dist.P2POp(dist.isend, cur, nxt_rank, self.group), dist.P2POp(dist.irecv, recv_buf, prv_rank, self.group)]
+                send_buf = cur if self.virtual is None else self.virtual[(r - h - 1) % P]
+                ops = [dist.P2POp(dist.isend, send_buf, nxt_rank, self.group), dist.P2POp(dist.irecv, recv_buf, prv_rank, self.group)]
                 reqs = dist.batch_isend_irecv(ops)   # posted before the kernel so it runs beside it
             probe = self.hop_probe if (reqs is not None and self.hop_probe is not None and self.hop_probe.enabled) else None
             if probe is not None:
