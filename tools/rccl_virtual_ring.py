@@ -1,0 +1,40 @@
+"""Rank 0's share of the multi-GPU headline run, with the REAL RCCL transport, on one GPU: `ShardedEngine(virtual_world=P)` — the one real rank plays
+rank 0 of a P-rank ring and passes the other ranks' source blocks through the communicator to itself (tests/test_gpu_rccl.py). Prints, for P = 1, 2, 4, 8 at
+N = 2^20 fp32 (BASELINE configs[2] shapes): time per force evaluation of rank 0's N/P sinks against all N sources, per-hop exchange time, the kernel it overlaps
+and the part of the exchange the compute stream had to wait for. What this cannot show is the xGMI link itself (a self send is a device-local copy).
+usage: rccl_virtual_ring.py [n] [f32|f64]"""
+import json, os, sys, time
+import numpy as np
+import torch
+import torch.distributed as dist
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bachelor_thesis_n_body_amd as nb
+from bachelor_thesis_n_body_amd.dist import HopProbe
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+dtype = np.float64 if (len(sys.argv) > 2 and sys.argv[2] == "f64") else np.float32
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+s = nb.plummer_sphere(n, 0, dtype)
+for P in (1, 2, 4, 8):
+    eng = nb.ShardedEngine(n, dtype, device=dev, virtual_world=P if P > 1 else 0)
+    eng.set_state(s)
+    probe = HopProbe(torch, dev); eng.hop_probe = probe
+    for _ in range(2):
+        eng.accel(0.01)
+    torch.cuda.synchronize()
+    probe.enabled = P > 1
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.accel(0.01)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ps = probe.summary() or {}
+    print(json.dumps({"virtual_ranks": P, "n": n, "dtype": np.dtype(dtype).name, "sinks_of_rank0": eng.n_loc, "ms_per_force_evaluation": dt * 1e3,
+                      "interactions_per_s_of_this_rank": eng.n_loc * float(n) / dt, "projected_whole_job_interactions_per_s": P * eng.n_loc * float(n) / dt,
+                      "hop_comm_ms": ps.get("comm_ms"), "hop_kernel_ms": ps.get("kernel_ms"), "hop_exposed_ms": ps.get("exposed_ms")}), flush=True)
+dist.destroy_process_group()
