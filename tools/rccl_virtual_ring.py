@@ -17,7 +17,10 @@ dtype = np.float64 if (len(sys.argv) > 2 and sys.argv[2] == "f64") else np.float
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+hp = os.environ.get("NB_RCCL_HIGH_PRIORITY", "1") != "0"
+opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=hp)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=opts)
+print(json.dumps({"communicator_stream_high_priority": hp}), flush=True)
 s = nb.plummer_sphere(n, 0, dtype)
 for P in (1, 2, 4, 8):
     eng = nb.ShardedEngine(n, dtype, device=dev, virtual_world=P if P > 1 else 0)
