@@ -298,9 +298,10 @@ def run_rungs(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: 
     """Comoving P3M run with CONCEPT's time-loop structure: base steps from `schedule` ("concept" = the steps its logs
     record, or an array of step sizes in Gyr), the mesh force kicking every particle once per base step, the short-range force through a
     rung hierarchy — a particle on rung l takes short-range kick-drift-kick steps of dt_base / 2^l (`nb_rung_step`). Rung limiter: the usual
-    dt_i = sqrt(2 eta eps_phys / |a_phys|) with physical softening a*eps and peculiar acceleration g / a^2, i.e. dt_i^2 = 2 eta eps a^3 / |g| in the code's
-    variables; `eta` = 0.018 is calibrated against the rung populations the reference's logs record: with it the fraction of particles above rung 0 follows the logged curve from 0.01 % (a = 0.31) to
-    6 % (a = 0.87) within ~20 %, and the split over rungs 1 / 2 at step 138 reads 1 300 / 450 against the logs' 1 418 / 695 (tests/test_gpu_rungs.py). Returns (pos, vel[, populations per step])."""
+    dt_i = sqrt(2 eta eps_phys / |a_phys|) with physical softening a*eps and the peculiar acceleration g / a^2 of the SHORT-RANGE force alone (CONCEPT determines
+    its rung populations from the short-range interaction: …/params_id0200_*.log:42-46), i.e. dt_i^2 = 2 eta eps a^3 / |g_sr| in the code's variables; `eta` = 0.018 is calibrated against the rung populations the reference's logs record: with it the fraction of particles above rung 0 follows the logged curve
+    (0.8 % at a = 0.46, 2.5 % at 0.57, 5.2 % at 0.70, 6.1 % at 0.87) to a few per cent, and the mean populations of rungs 1 / 2 / 3 over steps 130-141 read 1 276 / 532 / 21 against
+    the logs' 1 266 / 572 / 17 (tests/test_gpu_rungs.py). Returns (pos, vel[, populations per step])."""
     from .api import Engine
     from .state import State
     n = pos.shape[0]

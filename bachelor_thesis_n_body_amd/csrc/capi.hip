@@ -502,9 +502,12 @@ int nb_rung_step(nb_ctx* c, int levels, const double* kc, const double* dc, doub
     rc = force(2); if (rc) return rc;
     c->lr_valid = true;
   }
-  // rungs from the total acceleration at the start of the base step
+  // rungs from the short-range acceleration at the start of the base step
   NB_HIP(c, hipMemsetAsync(c->rung_hist, 0, 16 * sizeof(int), c->stream));
-  rc = nb_launch_rung_assign(c, c->dtype, ax, c->acc_lr, c->n, dt_base, crit, levels, c->rung, c->rung_hist); if (rc) return rc;
+  // the limiter takes the SHORT-RANGE acceleration alone — what CONCEPT's logs show ("Determining rung population ... P3M (short-range only)",
+  // …/params_id0200_*.log:42-46) and what reproduces its logged populations; NB_RUNG_SR_ONLY=0 uses the total acceleration instead
+  static const int sr_only = getenv("NB_RUNG_SR_ONLY") ? atoi(getenv("NB_RUNG_SR_ONLY")) : 1;
+  rc = nb_launch_rung_assign(c, c->dtype, ax, c->acc_lr, c->n, dt_base, crit, levels, sr_only, c->rung, c->rung_hist); if (rc) return rc;
   int hist[16];
   NB_HIP(c, hipMemcpyAsync(hist, c->rung_hist, sizeof(hist), hipMemcpyDeviceToHost, c->stream));
   NB_HIP(c, hipStreamSynchronize(c->stream));

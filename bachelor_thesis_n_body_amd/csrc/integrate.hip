@@ -80,13 +80,14 @@ kdk_post_kernel(T* __restrict__ vx, T* __restrict__ vy, T* __restrict__ vz, cons
 template <typename T>
 __global__ void __launch_bounds__(256)
 rung_assign_kernel(const T* __restrict__ sx, const T* __restrict__ sy, const T* __restrict__ sz, const T* __restrict__ lx,
-                   const T* __restrict__ ly, const T* __restrict__ lz, int64_t n, double dt_base, double crit, int levels,
+                   const T* __restrict__ ly, const T* __restrict__ lz, int64_t n, double dt_base, double crit, int levels, int sr_only,
                    unsigned char* __restrict__ rung, int* __restrict__ hist) {
   __shared__ int h[16];
   if (threadIdx.x < 16) h[threadIdx.x] = 0;
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double gx = (double)sx[i] + (double)lx[i], gy = (double)sy[i] + (double)ly[i], gz = (double)sz[i] + (double)lz[i];
+    const double wl = sr_only ? 0.0 : 1.0;
+    const double gx = (double)sx[i] + wl * (double)lx[i], gy = (double)sy[i] + wl * (double)ly[i], gz = (double)sz[i] + wl * (double)lz[i];
     const double g = sqrt(gx * gx + gy * gy + gz * gz);
     const double dti = g > 0.0 ? sqrt(crit / g) : 1e300;
     int l = 0;
@@ -244,16 +245,16 @@ int nb_launch_kick_drift(nb_ctx* c, int dtype, void* x, void* y, void* z, void* 
   return NB_OK;
 }
 
-int nb_launch_rung_assign(nb_ctx* c, int dtype, const void* sr, const void* lr, int64_t n, double dt_base, double crit, int levels,
+int nb_launch_rung_assign(nb_ctx* c, int dtype, const void* sr, const void* lr, int64_t n, double dt_base, double crit, int levels, int sr_only,
                           unsigned char* rung, int* hist) {
   const size_t es = dtype == NB_F64 ? 8 : 4;
   const char *s = (const char*)sr, *l = (const char*)lr;
   if (dtype == NB_F32)
     rung_assign_kernel<float><<<stream_grid(n), 256, 0, c->stream>>>((const float*)s, (const float*)(s + n * es), (const float*)(s + 2 * n * es),
-                                                                     (const float*)l, (const float*)(l + n * es), (const float*)(l + 2 * n * es), n, dt_base, crit, levels, rung, hist);
+                                                                     (const float*)l, (const float*)(l + n * es), (const float*)(l + 2 * n * es), n, dt_base, crit, levels, sr_only, rung, hist);
   else
     rung_assign_kernel<double><<<stream_grid(n), 256, 0, c->stream>>>((const double*)s, (const double*)(s + n * es), (const double*)(s + 2 * n * es),
-                                                                      (const double*)l, (const double*)(l + n * es), (const double*)(l + 2 * n * es), n, dt_base, crit, levels, rung, hist);
+                                                                      (const double*)l, (const double*)(l + n * es), (const double*)(l + 2 * n * es), n, dt_base, crit, levels, sr_only, rung, hist);
   NB_HIP(c, hipGetLastError());
   return NB_OK;
 }

@@ -122,7 +122,7 @@ int nb_launch_kick(nb_ctx* c, int dtype, void* vx, void* vy, void* vz, const voi
                    const void* az, int64_t n, double h);
 int nb_launch_drift(nb_ctx* c, int dtype, void* x, void* y, void* z, const void* vx, const void* vy,
                     const void* vz, int64_t n, double dt);
-int nb_launch_rung_assign(nb_ctx* c, int dtype, const void* sr, const void* lr, int64_t n, double dt_base, double crit, int levels,
+int nb_launch_rung_assign(nb_ctx* c, int dtype, const void* sr, const void* lr, int64_t n, double dt_base, double crit, int levels, int sr_only,
                           unsigned char* rung, int* hist);
 int nb_launch_rung_kick(nb_ctx* c, int dtype, void* vx, void* vy, void* vz, const void* ax, const void* ay, const void* az,
                         const unsigned char* rung, int64_t n, int phase, int s, int S, int top, const double* kc);

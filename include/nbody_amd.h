@@ -114,8 +114,8 @@ int nb_kdk_run(nb_ctx* ctx, int64_t nsteps, const double* kick1, const double* d
 /* One BASE step of a comoving P3M run with a rung hierarchy for the short-range force — the structure of CONCEPT's time loop as its logs show it
  * (…/params_id0200_*.log:56-96): the mesh force kicks every particle over the base step (half at its start, half at its end); a
  * particle on rung l receives its short-range kicks in steps of dt_base / 2^l (kick-drift-kick per rung step); all particles drift with the finest
- * populated step and the short-range force is re-evaluated after every drift. Rungs are assigned at the start of the step from the total acceleration
- * g = a_sr + a_lr: the lowest l < levels with dt_base / 2^l <= sqrt(crit / |g|)  (crit = 2 eta eps a^3 for the usual sqrt(2 eta eps_phys / |a_phys|) limiter in
+ * populated step and the short-range force is re-evaluated after every drift. Rungs are assigned at the start of the step from the short-range acceleration
+ * g = a_sr (as CONCEPT determines its rung populations: …/params_id0200_*.log:42-46): the lowest l < levels with dt_base / 2^l <= sqrt(crit / |g|)  (crit = 2 eta eps a^3 for the usual sqrt(2 eta eps_phys / |a_phys|) limiter in
  * the comoving variables of nb_kdk_step). kc / dc: the cumulative kick integral int dt/a and drift integral int dt/a^2 from the start of the base step to each
  * of the 2 * 2^(levels-1) + 1 boundaries of its finest half-sub-steps (host arrays). populations[l] (may be NULL) returns the rung populations. P3M contexts only. */
 int nb_rung_step(nb_ctx* ctx, int levels, const double* kc, const double* dc, double dt_base, double crit, double eps, double G,
