@@ -11,7 +11,7 @@ k_ref, p_lin = pp[:, 0], pp[:, 4]
 slope = np.log(p_lin[-1] / p_lin[-3]) / np.log(k_ref[-1] / k_ref[-3])
 k_ext = np.geomspace(k_ref[-1] * 1.05, 1.0, 12)
 tab = np.column_stack([np.concatenate([k_ref, k_ext]), np.concatenate([p_lin, p_lin[-1] * (k_ext / k_ref[-1]) ** slope])])
-n_side, L = 32, 500.0
+n_side, L = (int(sys.argv[2]) if len(sys.argv) > 2 else 32), 500.0
 c = cosmo.Cosmology.from_h_omegas(0.6736, 0.02237, 0.12)
 nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 
@@ -20,7 +20,7 @@ def job(i, times):
     t0 = time.perf_counter()
     pos, vel = cosmo.zeldovich_ics(tab, n_side, L, c, 0.02, 300 + i, 9000 + i, lpt=2)
     t1 = time.perf_counter()
-    pos, vel = cosmo.run_pp(pos, vel, c.particle_mass(L, n_side ** 3), L, c, 0.02, 1.0, nsteps, dtype=np.float32, gravity="p3m", ngrid=32)
+    pos, vel = cosmo.run_pp(pos, vel, c.particle_mass(L, n_side ** 3), L, c, 0.02, 1.0, nsteps, dtype=np.float32, gravity="p3m", ngrid=n_side)
     t2 = time.perf_counter()
     k, p = cosmo.power_modes(pos, L, n_side, interlace=True)
     d = field.delta_field(pos, L, n_side, subtract_mean=True)
