@@ -15,10 +15,10 @@ Everything computes on the GPU through libnbody_amd.so (include/nbody_amd.h); th
 """
 from .state import State
 from .ics import plummer_sphere, PLUMMER_A
-from .api import Engine, compute_forces, step, energy
+from .api import Engine, ClockProbe, compute_forces, step, energy
 from .dist import ShardedEngine, HipKernels, partition
 from . import field, grf, snapshot
 
-__all__ = ["State", "plummer_sphere", "PLUMMER_A", "Engine", "compute_forces", "step", "energy",
+__all__ = ["State", "plummer_sphere", "PLUMMER_A", "Engine", "ClockProbe", "compute_forces", "step", "energy",
            "ShardedEngine", "HipKernels", "partition", "field", "grf", "snapshot"]
 __version__ = "0.1.0"

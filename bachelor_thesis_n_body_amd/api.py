@@ -235,3 +235,28 @@ def energy(state: State, eps: float, G: float = 1.0, dtype=None, device: int = 0
     with Engine(state.n, d, device) as e:
         e.set_state(state)
         return e.energy(eps, G)
+
+
+class ClockProbe:
+    """Sustained shader clock of one GPU over a time window (nb_clock_probe_begin / _end): start it, launch the kernels of interest,
+    then `mhz, window_ms = probe.end()`. A measurement aid for bench.py's roofline line; no counterpart in the reference."""
+
+    def __init__(self, device: int, window_ms: float):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        _lib.check(None, self._lib.nb_clock_probe_begin(int(device), float(window_ms), C.byref(self._h)), "nb_clock_probe_begin")
+
+    def end(self) -> Tuple[float, float]:
+        if not self._h:
+            raise RuntimeError("ClockProbe.end() called twice")
+        mhz, win = C.c_double(), C.c_double()
+        h, self._h = self._h, C.c_void_p()
+        _lib.check(None, self._lib.nb_clock_probe_end(h, C.byref(mhz), C.byref(win)), "nb_clock_probe_end")
+        return mhz.value, win.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                self.end()
+            except Exception:
+                pass

@@ -39,6 +39,7 @@ sys.path.insert(0, str(ROOT))
 FLOP_PER_INTERACTION = 20.0        # Nyland-Harris-Prins convention, SURVEY.md §8(d)
 PEAK_FP32_VECTOR_TFLOPS = 157.3    # MI355X_MICROARCH.md "Peak FP32 (vector)"
 PEAK_FP64_VECTOR_TFLOPS = 78.6
+PEAK_CLOCK_MHZ = 2400.0            # the clock both peaks are quoted at (256 CUs x 256 flop/clk x 2.4 GHz)
 
 
 def measured_traffic():
@@ -306,9 +307,18 @@ def main():
             torch.cuda.synchronize()
 
     eng.accel(eps, G)                      # initial a(x): not part of a step
+    warm_step_s = None
     for _ in range(args.warmup):
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
         eng.step(dt, 1, eps, G)
+        torch.cuda.synchronize()
+        tw = time.perf_counter() - tw
+        warm_step_s = tw if warm_step_s is None else min(warm_step_s, tw)
     sync()
+    # sustained shader clock of this rank's GPU over ~80 % of the timed region (one sleeping wave on a private stream, nb_clock_probe_*):
+    # boxes differ by several per cent in the clock they hold under this kernel; cycles per interaction is the box-independent figure
+    clock = nb.ClockProbe(local_rank, min(5000.0, max(1.0, 0.8e3 * warm_step_s * args.steps))) if warm_step_s else None
     timer.enabled = True
     if probe is not None:
         probe.enabled = True
@@ -320,10 +330,13 @@ def main():
     timer.enabled = False
     if probe is not None:
         probe.enabled = False
+    clock_mhz, clock_ms = clock.end() if clock is not None else (None, None)
+    clock_min = clock_mhz
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed, -(clock_mhz or 0.0)], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        clock_min = -float(t[1].item()) if clock_mhz else None
 
     interactions = float(args.n) * float(args.n) * args.steps
     value = interactions / elapsed
@@ -366,6 +379,15 @@ def main():
                          "traffic_source": "NOT measured in this run: HBM bytes per launch from the rocprofv3 --pmc passes of this same command committed as profiles/r02_bench_n1_uniform_rocprofv3_summary.txt (FETCH_SIZE x2 + WRITE_SIZE; 0.4 GB = the fp64 slab of the 8-way source split); algorithmic bytes = 28*N"},
         }
         r = out["roofline"]
+        if clock_mhz:
+            simds = 256 * 4
+            r["sustained_clock_mhz"] = clock_mhz
+            r["clock_window_ms"] = clock_ms
+            if world > 1:
+                r["sustained_clock_mhz_min_over_ranks"] = clock_min
+            # the peak is quoted at 2 400 MHz; what this box could have reached at the clock it actually held
+            r["frac_at_sustained_clock"] = achieved / (peak * clock_mhz / PEAK_CLOCK_MHZ)
+            r["cycles_per_64_interactions_per_simd"] = (k_ms * 1e-3 * clock_mhz * 1e6 * simds / (k_inter / 64.0)) if k_inter > 0 else None
         profile_note = r["traffic_source"]
         r["algorithmic_bytes_per_launch"] = (28 if args.dtype == "f32" else 56) * args.n
         if world > 1 or args.traffic == "none":

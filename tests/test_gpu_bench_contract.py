@@ -32,6 +32,10 @@ def test_bench_prints_one_contract_json_line():
     # HBM traffic measured live (two rocprofv3 --pmc child passes of the same command), not read from a committed file
     assert r["traffic_source"].startswith("measured in this run"), r["traffic_source"]
     assert r["traffic"] > r["algorithmic_bytes_per_launch"] == 28 * 65536
+    # the shader clock held during the timed region, and the box-independent cycles per 64 interactions and SIMD (issue floor: 30)
+    assert 1200.0 < r["sustained_clock_mhz"] < 2600.0 and r["clock_window_ms"] > 0
+    assert r["frac_at_sustained_clock"] == pytest.approx(r["frac"] * 2400.0 / r["sustained_clock_mhz"])
+    assert 28.0 < r["cycles_per_64_interactions_per_simd"] < 80.0
 
 
 def test_bench_general_mass_variant_is_labelled():
@@ -59,6 +63,7 @@ def test_bench_two_ranks_self_launched_on_one_gpu(dtype):
     r = j["roofline"]
     assert r["launches_timed"] == 6 and r["interactions_per_launch"] == 32768.0 ** 2 and 0.05 < r["frac"] < 1.0
     assert "cpu_baseline" not in j          # rank 0 at N = 1 only
+    assert 1200.0 < r["sustained_clock_mhz_min_over_ranks"] <= r["sustained_clock_mhz"] * 1.2
 
 
 def test_bench_propagates_a_failing_rank():
@@ -75,3 +80,24 @@ def test_bench_single_process_multi_device_context():
     j = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
     assert j["n_gpus"] == 2 and "nb_create_multi" in j["config"]["parallelism"] and j["value"] == pytest.approx(65536 ** 2 * 3 / (j["ms_per_step"] * 3e-3), rel=1e-6)
     assert 0.05 < j["roofline"]["frac"] * 2 < 1.0          # two shards share one GPU here
+
+
+def test_clock_probe_measures_a_plausible_shader_clock():
+    """nb_clock_probe_begin / _end: one sleeping wave, cycles over the constant-rate counter; beside a running all-pairs launch."""
+    import numpy as np
+    import bachelor_thesis_n_body_amd as nb
+    n = 1 << 17
+    with nb.Engine(n, np.float32) as e:
+        e.set_state(nb.plummer_sphere(n, 0, np.float32))
+        e.accel(0.01, fetch=False)
+        probe = nb.ClockProbe(0, 20.0)
+        for _ in range(6):
+            e.accel(0.01, fetch=False)
+        mhz, window = probe.end()
+    assert 1200.0 < mhz < 2600.0 and 20.0 <= window < 40.0
+    with pytest.raises(RuntimeError):
+        probe.end()
+    with pytest.raises(RuntimeError):
+        nb.ClockProbe(99, 1.0)
+    with pytest.raises(RuntimeError):
+        nb.ClockProbe(0, 0.0)

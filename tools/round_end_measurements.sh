@@ -15,5 +15,7 @@ python3 tools/bench_bh.py > $O/bench_bh.txt 2>&1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && export NB_NO_GRAPH=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_farm -- python3 tools/farm_job_profile.py 400 > $O/prof_farm.out 2>&1
 python3 tools/summarize_kernel_stats.py $O/prof_farm 16 > $O/farm_job_kernel_stats.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bh -- python3 tools/bench_bh.py 0.5 16777216 > $O/prof_bh.out 2>&1
+python3 tools/summarize_kernel_stats.py $O/prof_bh 14 > $O/bh_n16M_kernel_stats.txt 2>&1
 for f in $O/bench_*.json; do echo "$f: $(python3 -c "import json,sys; j=json.loads(open('$f').read().strip().splitlines()[-1]); print('%.4e int/s  %.3f ms/step  frac %.3f' % (j['value'], j['ms_per_step'], j['roofline']['frac']))")"; done
 head -6 $O/farm_job_profile.txt; cat $O/farm_job_kernel_stats.txt | head -6
