@@ -46,7 +46,7 @@ struct BHBuf {
   int2* range = nullptr;                     // all nodes: (first, count)
   float4* com = nullptr;                     // all nodes: (cx, cy, cz, mass)
   float* l2 = nullptr;                       // all nodes: cell edge squared
-  float* out = nullptr;                      // [3][n] accelerations in sorted order
+  float4* pk = nullptr;                      // (x,y,z,m) in the caller's order: one 16-byte read per particle for the gather
   int4* rec = nullptr;                       // all nodes: (l2 bits, first, count, left child) for the list walk
   int* gstack = nullptr;                     // wave-private stacks of the persistent list-walk waves
   int stack_blocks = 0;                      // blocks gstack was sized for: the list walk never launches more
@@ -104,8 +104,8 @@ __global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, fl
 }
 
 __global__ void __launch_bounds__(256)
-morton_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
-              const float* __restrict__ bbox, unsigned long long* __restrict__ keys, int* __restrict__ idx) {
+morton_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ m, int n,
+              const float* __restrict__ bbox, unsigned long long* __restrict__ keys, int* __restrict__ idx, float4* __restrict__ pk) {
   const float edge = bbox[6];
   const float scale = 2097152.0f / edge;   // 2^21 cells per axis
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -119,16 +119,14 @@ morton_kernel(const float* __restrict__ x, const float* __restrict__ y, const fl
     }
     keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
     idx[i] = i;
+    pk[i] = make_float4(v[0], v[1], v[2], m[i]);
   }
 }
 
 __global__ void __launch_bounds__(256)
-gather_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-              const float* __restrict__ m, const int* __restrict__ idx, int n, float4* __restrict__ sp,
-              double* __restrict__ pre) {
+gather_kernel(const float4* __restrict__ pk, const int* __restrict__ idx, int n, float4* __restrict__ sp, double* __restrict__ pre) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int j = idx[i];
-    const float4 p = make_float4(x[j], y[j], z[j], m[j]);
+    const float4 p = pk[idx[i]];
     sp[i] = p;
     const double mm = (double)p.w;
     pre[i] = mm; pre[(size_t)n + i] = mm * (double)p.x; pre[2 * (size_t)n + i] = mm * (double)p.y; pre[3 * (size_t)n + i] = mm * (double)p.z;
@@ -211,7 +209,8 @@ template <bool GUARD>
 __global__ void __launch_bounds__(256)
 walk_kernel(const float4* __restrict__ sp, int n, const int2* __restrict__ child, const int2* __restrict__ range,
             const float4* __restrict__ com, const float* __restrict__ l2, float theta2, float eps2,
-            float* __restrict__ out, int* __restrict__ flags) {
+            const int* __restrict__ idx, float G, float* __restrict__ out_x, float* __restrict__ out_y, float* __restrict__ out_z,
+            int* __restrict__ flags) {
   __shared__ int stack_all[4][STACK];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   volatile int* stack = stack_all[wave];
@@ -259,7 +258,7 @@ walk_kernel(const float4* __restrict__ sp, int n, const int2* __restrict__ child
       } else if (lane == 0) flags[0] = 1;                                    // overflow: results invalid, reported by the host
     }
   }
-  if (live) { out[i] = ax; out[(size_t)n + i] = ay; out[2 * (size_t)n + i] = az; }
+  if (live) { const int j = idx[i]; out_x[j] = G * ax; out_y[j] = G * ay; out_z[j] = G * az; }   // straight to the caller's particle order
 }
 
 constexpr int LSTACK = 12288;      // entries per wave-private stack (<= 128 nodes left behind per tree level, depth <= 96)
@@ -279,8 +278,8 @@ constexpr int LSTACK = 12288;      // entries per wave-private stack (<= 128 nod
 template <bool GUARD>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB_BH_WPE, NB_BH_WPE)))
 walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict__ com, const int4* __restrict__ rec,
-                 float theta2, float eps2, float* __restrict__ out, int* __restrict__ gstack, int ngroups,
-                 int* __restrict__ flags, int nleaf) {
+                 float theta2, float eps2, const int* __restrict__ idx, float G, float* __restrict__ out_x, float* __restrict__ out_y,
+                 float* __restrict__ out_z, int* __restrict__ gstack, int ngroups, int* __restrict__ flags, int nleaf) {
   __shared__ float4 mono_all[4][64];
   __shared__ float4 tile_all[4][64];
   __shared__ float4 vlo_all[4][64];
@@ -427,19 +426,10 @@ walk_list_kernel(const float4* __restrict__ sp, int n, const float4* __restrict_
       }
       NB_WAVE_SYNC();                          // the lists are rewritten by the next pass
     }
-    if (live) { out[i] = ax; out[(size_t)n + i] = ay; out[2 * (size_t)n + i] = az; }
+    if (live) { const int j = idx[i]; out_x[j] = G * ax; out_y[j] = G * ay; out_z[j] = G * az; }   // straight to the caller's particle order
     NB_WAVE_SYNC();                            // the acceptance volumes are rewritten for the next group
   }
 #undef NB_WAVE_SYNC
-}
-
-__global__ void __launch_bounds__(256)
-scatter_kernel(const float* __restrict__ sorted_out, const int* __restrict__ idx, int n, float G,
-               float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int j = idx[i];
-    ax[j] = G * sorted_out[i]; ay[j] = G * sorted_out[(size_t)n + i]; az[j] = G * sorted_out[2 * (size_t)n + i];
-  }
 }
 
 inline int grid_for(int64_t n) {
@@ -452,7 +442,7 @@ inline int grid_for(int64_t n) {
 struct nb_bh_state { BHBuf b; };
 
 static void bh_free(BHBuf& b) {
-  void* p[] = {b.bbox, b.keys, b.keys_sorted, b.idx, b.idx_sorted, b.sp, b.pre, b.child, b.range, b.com, b.l2, b.out, b.tmp,
+  void* p[] = {b.bbox, b.keys, b.keys_sorted, b.idx, b.idx_sorted, b.sp, b.pre, b.child, b.range, b.com, b.l2, b.pk, b.tmp,
                b.rec, b.gstack, b.flags};
   for (void* q : p) if (q) (void)hipFree(q);
   b = BHBuf();
@@ -496,7 +486,7 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
     NB_HIP(c, hipMalloc((void**)&b.range, T * sizeof(int2)));
     NB_HIP(c, hipMalloc((void**)&b.com, T * sizeof(float4)));
     NB_HIP(c, hipMalloc((void**)&b.l2, T * sizeof(float)));
-    NB_HIP(c, hipMalloc((void**)&b.out, 3 * N * sizeof(float)));
+    NB_HIP(c, hipMalloc((void**)&b.pk, N * sizeof(float4)));
     NB_HIP(c, hipMalloc((void**)&b.rec, T * sizeof(int4)));
     {
       const int groups = (int)((N + 63) / 64), blocks = (groups + 3) / 4 < 2048 ? (groups + 3) / 4 : 2048;
@@ -516,11 +506,11 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
   const int gb = grid_for(n) > 1024 ? 1024 : grid_for(n);
   bbox_partial_kernel<<<gb, 256, 0, st>>>(x, y, z, nn, part);
   bbox_final_kernel<<<1, 64, 0, st>>>(part, gb, b.bbox);
-  morton_kernel<<<grid_for(n), 256, 0, st>>>(x, y, z, nn, b.bbox, b.keys, b.idx);
+  morton_kernel<<<grid_for(n), 256, 0, st>>>(x, y, z, m, nn, b.bbox, b.keys, b.idx, b.pk);
   NB_HIP(c, hipGetLastError());
   size_t tb = b.tmp_bytes;
   NB_HIP(c, rocprim::radix_sort_pairs(b.tmp, tb, b.keys, b.keys_sorted, b.idx, b.idx_sorted, (size_t)n, 0, 63, st));
-  gather_kernel<<<grid_for(n), 256, 0, st>>>(x, y, z, m, b.idx_sorted, nn, b.sp, b.pre);
+  gather_kernel<<<grid_for(n), 256, 0, st>>>(b.pk, b.idx_sorted, nn, b.sp, b.pre);
   NB_HIP(c, hipGetLastError());
   for (int k = 0; k < 4; ++k) {
     tb = b.tmp_bytes;
@@ -533,8 +523,8 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
   const int blocks = (groups + 3) / 4;
   static const int walk_mode = getenv("NB_BH_WALK") ? atoi(getenv("NB_BH_WALK")) : 1;
   if (walk_mode == 0) {
-    if (eps2 > 0.f) walk_kernel<false><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out, b.flags);
-    else walk_kernel<true><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.out, b.flags);
+    if (eps2 > 0.f) walk_kernel<false><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.idx_sorted, G, ax, ay, az, b.flags);
+    else walk_kernel<true><<<blocks, 256, 0, st>>>(b.sp, nn, b.child, b.range, b.com, b.l2, theta * theta, eps2, b.idx_sorted, G, ax, ay, az, b.flags);
   } else {
     static const int maxb = getenv("NB_BH_BLOCKS") ? atoi(getenv("NB_BH_BLOCKS")) : 1792;   // 7 blocks per CU (VGPR-limited residency); <= 2048 (stack allocation)
     int pblocks = blocks < maxb ? blocks : maxb;            // persistent waves; groups are handed out dynamically
@@ -542,11 +532,9 @@ int nb_launch_accel_tree_f32(nb_ctx* c, const float* x, const float* y, const fl
     if (pblocks < 1) pblocks = 1;
     static const int nleaf = getenv("NB_BH_NLEAF") ? atoi(getenv("NB_BH_NLEAF")) : NLEAF_LIST;
     NB_HIP(c, hipMemsetAsync(b.flags + 1, 0, sizeof(int), st));                 // dynamic group counter
-    if (eps2 > 0.f) walk_list_kernel<false><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.out, b.gstack, groups, b.flags, nleaf);
-    else walk_list_kernel<true><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.out, b.gstack, groups, b.flags, nleaf);
+    if (eps2 > 0.f) walk_list_kernel<false><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.idx_sorted, G, ax, ay, az, b.gstack, groups, b.flags, nleaf);
+    else walk_list_kernel<true><<<pblocks, 256, 0, st>>>(b.sp, nn, b.com, b.rec, theta * theta, eps2, b.idx_sorted, G, ax, ay, az, b.gstack, groups, b.flags, nleaf);
   }
-  NB_HIP(c, hipGetLastError());
-  scatter_kernel<<<grid_for(n), 256, 0, st>>>(b.out, b.idx_sorted, nn, G, ax, ay, az);
   NB_HIP(c, hipGetLastError());
   return NB_OK;
 }
