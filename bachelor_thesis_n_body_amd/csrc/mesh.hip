@@ -48,6 +48,8 @@ struct nb_mesh_state {
   void* sorted = nullptr;            // {x, y, z, m} per particle in cell order, positions wrapped into [0, L)
   int ncell3_alloc = 0;
   int *cell_start = nullptr, *chunk_cnt = nullptr, *chunk_off = nullptr;
+  int4* chunk_info = nullptr;        // tile kernel: (row, first, last) per chunk
+  int64_t chunk_info_cap = 0;
   void* tmp = nullptr;
   size_t tmp_bytes = 0;
   float* table = nullptr;            // long-range complement of the pair force tabulated in r^2 (fp32 short-range kernel)
@@ -392,6 +394,7 @@ __device__ inline double sr_factor(double r2, double eps2, double alpha, double 
 // contiguous memory segments (split where the periodic image changes). Images out of reach contribute nothing through the
 // cut-off test, so every sink sees each of its 27 neighbour-cell images exactly once.
 constexpr int SRW = 4;      // waves (= independent chunks) per block; they share only the look-up table
+constexpr int SRT = 8;      // the same for the tile kernel (its table is twice the size)
 
 // SOFT: eps > 0, so the softened term is finite for a coincident pair (the particle itself): no r = 0 guard in the loop (its dx = 0 kills the
 // term). UNI: all masses equal — the per-pair mass multiply is dropped and the common mass applied once with G at the end.
@@ -462,6 +465,13 @@ short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ k
         if ((a - (zlo - 1)) % zparts != zpart) { a = b + 1; continue; }
       }
       const T shz = (T)img * L;
+      // The periodic image: L is SUBTRACTED from whichever of the two lies next to the far face — from the source for a shift of -L, from
+      // the sinks (once per segment) for +L. x - L is exact for L/2 <= x <= 2L, so a close pair across a box face keeps its fp32 precision
+      // (adding +L to a source near 0 rounds it to ulp(L) = 8e-6 at L = 80: 4e-5 of the force of a pair 0.08 apart).
+      const T sox = shx < 0 ? shx : (T)0, soy = shy < 0 ? shy : (T)0, soz = shz < 0 ? shz : (T)0;
+      V4 ms[KS];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) { ms[k].x = me[k].x - (shx - sox); ms[k].y = me[k].y - (shy - soy); ms[k].z = me[k].z - (shz - soz); }
       const int b0 = cell_start[qbase + (a - img * nc)], b1 = cell_start[qbase + (b - img * nc) + 1];
       a = b + 1;
       for (int j0 = b0; j0 < b1; j0 += 64) {
@@ -469,7 +479,7 @@ short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ k
         const int j = j0 + lane;
         if (j < b1) {
           V4 s = sorted[j];
-          s.x += shx; s.y += shy; s.z += shz;
+          s.x += sox; s.y += soy; s.z += soz;
           tile[lane] = s;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // LDS serves a wave's accesses in order: the tile is visible
@@ -481,7 +491,7 @@ short_range_kernel(const V4* __restrict__ sorted, const uint32_t* __restrict__ k
             const V4 s = tile[e];                   // wave-uniform address: one LDS broadcast for all KS sink sets
 #pragma unroll
             for (int k = 0; k < KS; ++k) {
-              const T dx = s.x - me[k].x, dy = s.y - me[k].y, dz = s.z - me[k].z;
+              const T dx = s.x - ms[k].x, dy = s.y - ms[k].y, dz = s.z - ms[k].z;
               const T r2 = dx * dx + dy * dy + dz * dz;
               // wave-uniform branch: the 64 sinks of a set are a compact blob (sub-cell sort), most sources of the walked cells
               // are out of reach of all of them and cost only the distance test
@@ -540,6 +550,192 @@ sr_reduce_kernel(const double* __restrict__ part, int ny, const uint32_t* __rest
   }
   const uint32_t o = idx_s[i];
   ax[o] += (T)(G * sx); ay[o] += (T)(G * sy); az[o] += (T)(G * sz);
+}
+
+// ---- fp32 pair kernel on W-sink tiles (round 2) ----
+// The wave above tests every particle of 27 cells of edge >= r_cut against a 64-sink blob: at one particle per mesh cell and r_cut = 5.6
+// cells that is ~5 000 candidates for the ~740 partners a sink really has, and only 37 % of the lanes of a passing candidate do useful
+// work — a 64-particle blob plus its reach fills the 3^3 block whatever the sub-cell order. Here a wave owns only W (8 or 16) consecutive
+// sorted sinks — a blob a fraction of r_cut wide — and 64/W sources are in flight per step (lane = sink + W * slot: the W sinks are
+// replicated over the slots, slot t takes source e*S + t of the staged tile), so a step is still 64 pairs. The cells have edge
+// >= r_cut / 3 and the candidates are picked per neighbouring ROW of cells (fixed cx, cy: contiguous in memory along z) from the blob's
+// own bounding box: a row is skipped when its column is out of reach, and of the others only the z-interval within sqrt(r_cut^2 - d_xy^2)
+// of the box is walked — ~2 200 candidates per 8-sink blob instead of 5 000 per 64-sink one, at no per-candidate test or vote.
+// chunk k of the tile kernel -> (row, first sorted particle, last sorted particle): one binary search per chunk here, in a streaming
+// kernel, instead of 13 dependent loads at the start of every (short-lived) wave
+__global__ void __launch_bounds__(256)
+chunk_info_kernel(const int* __restrict__ cell_start, const int* __restrict__ chunk_off, int nrows, int nf, int W, int cap,
+                  int4* __restrict__ info) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cap) return;
+  if (k >= chunk_off[nrows]) { info[k] = make_int4(-1, 0, -1, 0); return; }   // the grid is an upper bound on the number of chunks
+  int lo = 0, hi = nrows;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= k) lo = mid; else hi = mid; }
+  const int i0 = cell_start[lo * nf] + (k - chunk_off[lo]) * W;
+  info[k] = make_int4(lo, i0, min(cell_start[(lo + 1) * nf], i0 + W) - 1, 0);
+}
+
+template <int W, bool SOFT, bool UNI>
+__global__ void __launch_bounds__(64 * SRT)
+short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict__ cell_start, const int4* __restrict__ chunk_info,
+                        int total, int nf, int reach, float L, float rcut, float eps2, double G,
+                        const uint32_t* __restrict__ idx_s, const float* __restrict__ table, float* __restrict__ ax,
+                        float* __restrict__ ay, float* __restrict__ az, const unsigned char* __restrict__ rung, int min_rung) {
+  constexpr int S = 64 / W;                    // sources in flight per step
+  constexpr int MAXSEG = 49 * 3 + 1;           // (2*3+1)^2 neighbouring rows x up to three periodic images along z
+  __shared__ float4 tiles[SRT][128];            // sources in reach of the blob: 64 being consumed + up to 63 waiting
+  __shared__ float2 tab2[TABN + 1];             // T(r^2) ~ tab2[i].x + tab2[i].y * t on t = r^2 * TABN / r_cut^2 in [i, i+1): index, one LDS read, one fma
+  __shared__ int seg_b0[SRT][MAXSEG], seg_cnt[SRT][MAXSEG], seg_img[SRT][MAXSEG];   // img: periodic image, 2 bits per axis (0: -L, 1: 0, 2: +L)
+  for (int t = threadIdx.x; t <= TABN; t += 64 * SRT) { const float t0 = table[t], d = table[t + 1] - t0; tab2[t] = make_float2(t0 - d * (float)t, d); }
+  __syncthreads();                              // the only block-wide step
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4* tile = tiles[wv];
+  const int w = blockIdx.x * SRT + wv;
+  if (w >= total) return;
+  const int4 ci = chunk_info[w];
+  const int row = ci.x, i_first = ci.y, i_last = ci.z;
+  if (row < 0) return;
+  const int cx = row / nf, cy = row % nf;
+  const int sk = lane & (W - 1), slot = lane / W;
+  const float4 me = sorted[min(i_first + sk, i_last)];   // padding sinks repeat the last one: inside the box, never stored
+  if (rung) {
+    const int i = i_first + sk;
+    if (__builtin_amdgcn_ballot_w64(i <= i_last && rung[idx_s[i]] >= min_rung) == 0) return;
+  }
+  // bounding box of the blob (every slot holds all W sinks)
+  float lox = me.x, loy = me.y, loz = me.z, hix = me.x, hiy = me.y, hiz = me.z;
+#pragma unroll
+  for (int o = 1; o < W; o <<= 1) {
+    lox = fminf(lox, __shfl_xor(lox, o)); loy = fminf(loy, __shfl_xor(loy, o)); loz = fminf(loz, __shfl_xor(loz, o));
+    hix = fmaxf(hix, __shfl_xor(hix, o)); hiy = fmaxf(hiy, __shfl_xor(hiy, o)); hiz = fmaxf(hiz, __shfl_xor(hiz, o));
+  }
+  // ---- candidate segments: lane (dx, dy) looks at one neighbouring row (still in box coordinates)
+  const int R = 2 * reach + 1;
+  const float c = L / (float)nf, invc = (float)nf / L, margin = 1e-4f * c, rc = rcut * 1.0001f;
+  int nmine = 0, sb0[3], scn[3], simg[3];
+  if (lane < R * R) {
+    int qx = cx + lane / R - reach, qy = cy + lane % R - reach;
+    const float colx = (float)qx * c, coly = (float)qy * c;          // the row's column, unwrapped
+    const float gx = fmaxf(0.f, fmaxf(colx - hix, lox - (colx + c)) - margin), gy = fmaxf(0.f, fmaxf(coly - hiy, loy - (coly + c)) - margin);
+    const float d2 = gx * gx + gy * gy;
+    if (d2 < rc * rc) {
+      const float rz = sqrtf(rc * rc - d2) + margin;
+      const int za = (int)floorf((loz - rz) * invc), zb = (int)floorf((hiz + rz) * invc);
+      int code = 1 | (1 << 2);
+      if (qx < 0) { qx += nf; code = (code & ~3) | 0; } else if (qx >= nf) { qx -= nf; code = (code & ~3) | 2; }
+      if (qy < 0) { qy += nf; code = (code & ~12) | (0 << 2); } else if (qy >= nf) { qy -= nf; code = (code & ~12) | (2 << 2); }
+      const int qbase = (qx * nf + qy) * nf;
+      for (int img = -1; img <= 1; ++img) {
+        const int a = max(za, img * nf), b = min(zb, img * nf + nf - 1);
+        if (a > b) continue;
+        const int b0 = cell_start[qbase + a - img * nf], b1 = cell_start[qbase + b - img * nf + 1];
+        if (b1 > b0) { sb0[nmine] = b0; scn[nmine] = b1 - b0; simg[nmine] = code | ((img + 1) << 4); ++nmine; }
+      }
+    }
+  }
+  int nseg = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(nmine > k);
+    if (nmine > k) {
+      const int pos = nseg + __popcll(mk & ((1ull << lane) - 1ull));
+      seg_b0[wv][pos] = sb0[k]; seg_cnt[wv][pos] = scn[k]; seg_img[wv][pos] = simg[k];
+    }
+    nseg += __popcll(mk);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const float rcut2 = rcut * rcut, tscale = (float)TABN / rcut2;
+  const float far = 1e18f;
+  // From here on coordinates are relative to the low corner of the blob's box: a source that reaches the sinks through a periodic image
+  // is shifted by (image - corner), a small number, instead of by +-L — in fp32 a close pair across a box face keeps the precision it
+  // has anywhere else (with the plain +-L shift it lost ulp(L) = 8e-6 of its separation).
+  // (Only for a blob narrower than r_cut: a straggling one — 16 particles of a void — would trade the exact differences of unshifted
+  // coordinates for rounding at the scale of its own extent; it keeps box coordinates.)
+  const bool compact = fmaxf(fmaxf(hix - lox, hiy - loy), hiz - loz) < rcut;
+  const float ox = compact ? lox : 0.f, oy = compact ? loy : 0.f, oz = compact ? loz : 0.f;
+  const float4 mel = make_float4(me.x - ox, me.y - oy, me.z - oz, me.w);
+  const float ax0 = lox - ox, ay0 = loy - oy, az0 = loz - oz, bx = hix - ox, by = hiy - oy, bz = hiz - oz;   // the box in those coordinates
+  double tx = 0.0, ty = 0.0, tz = 0.0;
+  // `steps` steps over buf[0 .. steps*S): S sources per step, one per slot
+  auto consume = [&](int steps) {
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    for (int e = 0; e < steps; e += 2) {                     // two steps per trip; an odd tail reads padding
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float4 q = tile[(e + u) * S + slot];
+        const float dx = q.x - mel.x, dy = q.y - mel.y, dz = q.z - mel.z;
+        const float r2 = dx * dx + dy * dy + dz * dz;
+        if (__builtin_amdgcn_ballot_w64(r2 < rcut2) == 0) continue;   // wave-uniform: no pair of this step in reach
+        const float t = r2 * tscale;                             // lanes beyond the cut-off read anything (or nothing: LDS reads out of
+        const float2 ab = tab2[(int)t];                          // range return 0) and are masked below
+        const float sinv = __builtin_amdgcn_rsqf(r2 + eps2);
+        const float soft = (SOFT || r2 > 0.f) ? sinv * sinv * sinv : 0.f;
+        float f = soft - fmaf(ab.y, t, ab.x);
+        if (!UNI) f *= q.w;
+        f = r2 < rcut2 ? f : 0.f;
+        fx = fmaf(f, dx, fx); fy = fmaf(f, dy, fy); fz = fmaf(f, dz, fz);
+      }
+    }
+    tx += (double)fx; ty += (double)fy; tz += (double)fz;
+  };
+  // The (segment, 64-source load) walk, flattened so that the global load of the next 64 sources is in flight while these are handled.
+  // Each loaded source is tested against the blob's bounding box (a quarter of an instruction per candidate and lane) and only those in
+  // reach of it are appended to the LDS buffer; 64 buffered sources are consumed at a time.
+  int sg = 0, j0 = 0, b0 = 0, cnt = 0, fill = 0;
+  float sx = 0.f, sy = 0.f, sz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+  auto open_segment = [&]() {
+    b0 = __builtin_amdgcn_readfirstlane(seg_b0[wv][sg]); cnt = __builtin_amdgcn_readfirstlane(seg_cnt[wv][sg]);
+    const int code = __builtin_amdgcn_readfirstlane(seg_img[wv][sg]);
+    // v + shift - origin in two exact steps: L is subtracted from whichever lies next to the far face (the source for a shift of -L: first
+    // term; the blob's origin for +L: second term), cf. the 64-sink kernel above
+    const float hx = (float)((code & 3) - 1) * L, hy = (float)(((code >> 2) & 3) - 1) * L, hz = (float)(((code >> 4) & 3) - 1) * L;
+    nx = fminf(hx, 0.f); ny = fminf(hy, 0.f); nz = fminf(hz, 0.f);
+    sx = fmaxf(hx, 0.f) - ox; sy = fmaxf(hy, 0.f) - oy; sz = fmaxf(hz, 0.f) - oz;
+    j0 = 0;
+  };
+  auto fetch = [&]() {
+    float4 v = make_float4(far, far, far, 0.f);              // lanes past the end of the segment: beyond every cut-off
+    if (j0 + lane < cnt) { v = sorted[b0 + j0 + lane]; v.x = (v.x + nx) + sx; v.y = (v.y + ny) + sy; v.z = (v.z + nz) + sz; }
+    return v;
+  };
+  float4 vnext = make_float4(far, far, far, 0.f);
+  if (nseg > 0) { open_segment(); vnext = fetch(); }
+  const float reach2 = rc * rc;
+  while (sg < nseg) {
+    const float4 v = vnext;
+    j0 += 64;
+    if (j0 >= cnt) { ++sg; if (sg < nseg) open_segment(); }
+    if (sg < nseg) vnext = fetch();
+    const float ex = fmaxf(fmaxf(ax0 - v.x, v.x - bx), 0.f), ey = fmaxf(fmaxf(ay0 - v.y, v.y - by), 0.f), ez = fmaxf(fmaxf(az0 - v.z, v.z - bz), 0.f);
+    const bool in = ex * ex + ey * ey + ez * ez < reach2;
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(in);
+    if (in) tile[fill + __popcll(mk & ((1ull << lane) - 1ull))] = v;
+    fill += __popcll(mk);
+    if (fill >= 64) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      consume(64 / S);
+      const float4 r = tile[64 + lane];                      // the overflow moves to the front
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      fill -= 64;
+      if (lane < fill) tile[lane] = r;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+  if (fill > 0) {
+    const int steps = (fill + S - 1) / S, padded = ((steps + 1) & ~1) * S;
+    if (lane + fill < padded) tile[fill + lane] = make_float4(far, far, far, 0.f);   // padded - fill < 2 S <= 64
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    consume(steps);
+  }
+  // the S slots of a sink, added in a fixed order
+#pragma unroll
+  for (int o = W; o < 64; o <<= 1) { tx += __shfl_xor(tx, o); ty += __shfl_xor(ty, o); tz += __shfl_xor(tz, o); }
+  const int i = i_first + sk;
+  if (slot == 0 && i <= i_last) {
+    const double g = UNI ? G * (double)sorted[0].w : G;
+    const uint32_t o = idx_s[i];
+    ax[o] += (float)(g * tx); ay[o] += (float)(g * ty); az[o] += (float)(g * tz);
+  }
 }
 
 inline int stream_grid(int64_t n) {
@@ -601,6 +797,23 @@ int ensure_cells(nb_ctx* c, nb_mesh_state& s, int64_t n, int esz, int ncell3) {
 template <typename T, typename V4>
 int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z, const T* m, int64_t n, double L, int nc,
                 double alpha, double rcut, double eps2, double G, T* ax, T* ay, T* az) {
+  // fp32 and enough particles: the W-sink tile kernel on cells of edge >= r_cut / div, div = 3 or 2 — the finest with >= 4 particles per
+  // cell on average (emptier cells mean many short segments per blob: measured slower than the 64-sink kernel below). NB_SR_TILES=0/1
+  // forces it off/on, NB_SR_W (8 | 16) and NB_SR_DIV (1..3) choose the blob width and the cell size.
+  static const int tiles_env = getenv("NB_SR_TILES") ? atoi(getenv("NB_SR_TILES")) : -1;
+  static const int w_env = getenv("NB_SR_W") ? atoi(getenv("NB_SR_W")) : 0, div_env = getenv("NB_SR_DIV") ? atoi(getenv("NB_SR_DIV")) : 0;
+  const int tile_w = w_env == 8 ? 8 : 16;
+  int reach = 0, nf = 0;
+  bool use_tiles = false;
+  if (sizeof(T) == 4 && tiles_env != 0 && (tiles_env > 0 || n >= 262144)) {
+    const int d_hi = (div_env >= 1 && div_env <= 3) ? div_env : 3, d_lo = (div_env >= 1 && div_env <= 3) ? div_env : 2;
+    for (int d = d_hi; d >= d_lo && !use_tiles; --d) {
+      const int f = (int)floor((double)d * L / rcut);
+      const double f3 = (double)f * f * f;
+      if (f >= 2 * d + 2 && f3 <= 6.0e7 && (tiles_env > 0 || (double)n >= 4.0 * f3)) { reach = d; nf = f; use_tiles = true; }
+    }
+  }
+  if (use_tiles) nc = nf;
   const int ncell3 = nc * nc * nc;
   int rc = ensure_cells(c, s, n, (int)sizeof(T), ncell3);
   if (rc) return rc;
@@ -621,7 +834,7 @@ int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z,
   // sinks per lane (chunk = 64 * ks particles): 2 halves the LDS broadcasts per pair; with very full cells (the Ewald cut-off:
   // thousands of particles per cell, hardly any source out of reach of a 64-sink blob) 1 measured 6 % faster
   const int ks = (ks_env == 1 || ks_env == 2 || ks_env == 4) ? ks_env : (n / ncell3 >= 1024 ? 1 : 2);
-  const int chunk = 64 * ks;
+  const int chunk = use_tiles ? tile_w : 64 * ks;
   chunk_count_kernel<<<(nrows + 1 + 255) / 256, 256, 0, st>>>(s.cell_start, nrows, nc, chunk, s.chunk_cnt);
   NB_HIP(c, hipGetLastError());
   tb = s.tmp_bytes;
@@ -632,6 +845,29 @@ int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z,
     sr_table_kernel<<<(TABN + 2 + 255) / 256, 256, 0, st>>>(s.table, alpha, rcut * rcut);
     NB_HIP(c, hipGetLastError());
     s.table_alpha = alpha; s.table_rcut = rcut;
+  }
+  if constexpr (sizeof(T) == 4) {
+    if (use_tiles) {
+      if (s.chunk_info_cap < max_chunks) {
+        NB_HIP(c, hipStreamSynchronize(st));
+        if (s.chunk_info) { (void)hipFree(s.chunk_info); s.chunk_info = nullptr; s.chunk_info_cap = 0; }
+        NB_HIP(c, hipMalloc((void**)&s.chunk_info, (size_t)(max_chunks + max_chunks / 8) * sizeof(int4)));
+        s.chunk_info_cap = max_chunks + max_chunks / 8;
+      }
+      chunk_info_kernel<<<(unsigned)((max_chunks + 255) / 256), 256, 0, st>>>(s.cell_start, s.chunk_off, nrows, nc, tile_w, (int)max_chunks, s.chunk_info);
+      NB_HIP(c, hipGetLastError());
+      const unsigned gridx = (unsigned)((max_chunks + SRT - 1) / SRT);
+      const bool soft_t = eps2 > 0.0 && (float)eps2 > 1e-30f, uni_t = c->uniform_mass;
+#define NB_ST2(WW, SF, UN) short_range_tile_kernel<WW, SF, UN><<<gridx, 64 * SRT, 0, st>>>((const float4*)s.sorted, s.cell_start, s.chunk_info, (int)max_chunks, \
+    nc, reach, (float)L, (float)rcut, (float)eps2, G, s.idx_s, s.table, ax, ay, az, c->sr_rung, c->sr_min_rung)
+#define NB_ST(WW) do { if (soft_t && uni_t) NB_ST2(WW, true, true); else if (soft_t) NB_ST2(WW, true, false); else if (uni_t) NB_ST2(WW, false, true); \
+                       else NB_ST2(WW, false, false); } while (0)
+      if (tile_w == 16) NB_ST(16); else NB_ST(8);
+#undef NB_ST
+#undef NB_ST2
+      NB_HIP(c, hipGetLastError());
+      return NB_OK;
+    }
   }
   // fewer chunks than ~4 waves per SIMD: one wave per (chunk, neighbouring row, z-part) — 9 x zparts the waves, each that fraction of the
   // serial walk (the 32^3 farm jobs of the thesis: 256 chunks; short-range kernel 1.41 ms -> see DESIGN.md §6.7); partial sums go
@@ -754,7 +990,7 @@ void nb_mesh_release(nb_ctx* c) {
   for (auto& g : s.grid) if (g) (void)hipFree(g);
   if (s.have_fft) (void)hipfftDestroy(s.fft);
   for (void* p : {(void*)s.keys, (void*)s.keys_s, (void*)s.idx, (void*)s.idx_s, s.sorted, (void*)s.cell_start,
-                  (void*)s.chunk_cnt, (void*)s.chunk_off, s.tmp, (void*)s.table})
+                  (void*)s.chunk_cnt, (void*)s.chunk_off, s.tmp, (void*)s.table, (void*)s.chunk_info})
     if (p) (void)hipFree(p);
   delete c->mesh;
   c->mesh = nullptr;

@@ -178,6 +178,43 @@ def test_long_range_through_lds_bricks_matches_oracle(ngrid, interlace, dtype):
     assert np.abs(got - ref).max() < (1e-9 if dtype == np.float64 else 5e-6) * _scale(ref)
 
 
+@pytest.mark.parametrize("eps", [0.15, 0.0])
+@pytest.mark.parametrize("equal_masses", [True, False])
+@pytest.mark.parametrize("clustered", [False, True])
+def test_short_range_tile_kernel_matches_oracle(eps, equal_masses, clustered):
+    """fp32, >= 262 144 particles and >= 4 per cell of edge r_cut/3: the pair sum runs on 16-sink tiles (candidate segments from the blob's
+    bounding box, sources culled against it and compacted in LDS). Sampled sinks — among them the ones next to the box faces, whose
+    partners are periodic images — against the NumPy oracle, for the four instantiations of the kernel."""
+    n, L, ngrid = 300000, 80.0, 48
+    pos, mr = _cloud(n, L, 11, clustered=clustered)
+    m = np.full(n, 0.75) if equal_masses else mr
+    p = pos.astype(np.float32).astype(np.float64); mm = m.astype(np.float32).astype(np.float64)
+    rs = 1.25 * L / ngrid
+    got = _accel(pos, m, np.float32, L, "p3m", ngrid, eps, part="short")
+    near_face = np.argsort(np.minimum(p, L - p).min(1))[:64]
+    idx = np.unique(np.concatenate([np.random.default_rng(2).choice(n, 192, replace=False), near_face]))
+    ref = mo.short_range_accel(p, mm, L, rs, 4.5 * rs, eps, sinks=idx)
+    assert np.isfinite(got).all()
+    assert np.abs(got[idx] - ref).max() < 3e-5 * _scale(ref)
+
+
+def test_close_pair_across_a_box_face_keeps_fp32_precision():
+    """Two particles 0.08 apart on either side of the face z = L, in a box of L = 80 (fp32 ulp(L) = 8e-6): the pair kernels work in
+    coordinates relative to the sink blob, so the image shift is a small number and the separation keeps its precision — with a plain +-L
+    shift the force of this pair was off by 4e-5 of its size."""
+    L, ngrid, eps = 80.0, 48, 0.15
+    rs = 1.25 * L / ngrid
+    for n in (2000, 300000):                      # the 64-sink kernel and the 16-sink tile kernel
+        pos, _ = _cloud(n, L, 21)
+        pos[0] = (64.74076843, 31.28139877, 79.99965668)
+        pos[1] = (64.66902160, 31.25299840, 0.02958335)
+        m = np.full(n, 0.75)
+        p = pos.astype(np.float32).astype(np.float64)
+        got = _accel(pos, m, np.float32, L, "p3m", ngrid, eps, part="short")
+        ref = mo.short_range_accel(p, m, L, rs, 4.5 * rs, eps, sinks=np.array([0, 1]))
+        assert np.abs(got[:2] - ref).max() < 4e-6 * np.abs(ref).max(), n
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_short_range_random_configurations(seed):
     """Small random set-ups of the cell-list pair sum: few particles (all lanes of a block idle but a few), the minimum of 3 cells

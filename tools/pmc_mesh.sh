@@ -12,7 +12,7 @@ for sub in ("a", "b"):
     f = glob.glob(f"{sys.argv[1]}/{sub}/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(list)
     for row in csv.DictReader(open(f[0])):
-        if "short_range_kernel" in row["Kernel_Name"]:
+        if "short_range_kernel" in row["Kernel_Name"] or "short_range_tile_kernel" in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, v in sorted(acc.items()):
         print(f"{k:28s} {sum(v)/len(v):.4e}  (n={len(v)})")
