@@ -633,6 +633,11 @@ short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict
       }
     }
   }
+  int nloads = 0;                               // 64-source loads of the whole walk
+  for (int k = 0; k < nmine; ++k) nloads += (scn[k] + 63) >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) nloads += __shfl_xor(nloads, o);
+  nloads = __builtin_amdgcn_readfirstlane(nloads);
   int nseg = 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -665,7 +670,9 @@ short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict
         const float4 q = tile[(e + u) * S + slot];
         const float dx = q.x - mel.x, dy = q.y - mel.y, dz = q.z - mel.z;
         const float r2 = dx * dx + dy * dy + dz * dz;
-        if (__builtin_amdgcn_ballot_w64(r2 < rcut2) == 0) continue;   // wave-uniform: no pair of this step in reach
+        // wave-uniform: no pair of this step in reach (a third of the steps; measured without the vote — straight-line code, LDS reads of
+        // neighbouring steps overlapped: 256^3 23.2 -> 37.8 ms, 32^3 farm run 0.116 -> 0.124 s)
+        if (__builtin_amdgcn_ballot_w64(r2 < rcut2) == 0) continue;
         const float t = r2 * tscale;                             // lanes beyond the cut-off read anything (or nothing: LDS reads out of
         const float2 ab = tab2[(int)t];                          // range return 0) and are masked below
         const float sinv = __builtin_amdgcn_rsqf(r2 + eps2);
@@ -678,9 +685,11 @@ short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict
     }
     tx += (double)fx; ty += (double)fy; tz += (double)fz;
   };
-  // The (segment, 64-source load) walk, flattened so that the global load of the next 64 sources is in flight while these are handled.
-  // Each loaded source is tested against the blob's bounding box (a quarter of an instruction per candidate and lane) and only those in
-  // reach of it are appended to the LDS buffer; 64 buffered sources are consumed at a time.
+  // The (segment, 64-source load) walk: a scalar iterator runs PF loads ahead of the consumer, so PF global loads are in flight per wave
+  // (a wave makes ~50 loads, one per short segment: one at a time they are a chain of ~50 memory latencies, which a 32^3 system — a few
+  // waves per SIMD — cannot hide). Each loaded source is tested against the blob's bounding box (a quarter of an instruction per
+  // candidate and lane) and only those in reach of it are appended to the LDS buffer; 64 buffered sources are consumed at a time.
+  constexpr int PF = 4;
   int sg = 0, j0 = 0, b0 = 0, cnt = 0, fill = 0;
   float sx = 0.f, sy = 0.f, sz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
   auto open_segment = [&]() {
@@ -693,19 +702,17 @@ short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict
     sx = fmaxf(hx, 0.f) - ox; sy = fmaxf(hy, 0.f) - oy; sz = fmaxf(hz, 0.f) - oz;
     j0 = 0;
   };
-  auto fetch = [&]() {
+  auto fetch_next = [&]() {                                    // the iterator's next 64 sources (all padding once it is exhausted)
     float4 v = make_float4(far, far, far, 0.f);              // lanes past the end of the segment: beyond every cut-off
-    if (j0 + lane < cnt) { v = sorted[b0 + j0 + lane]; v.x = (v.x + nx) + sx; v.y = (v.y + ny) + sy; v.z = (v.z + nz) + sz; }
+    if (sg < nseg) {
+      if (j0 + lane < cnt) { v = sorted[b0 + j0 + lane]; v.x = (v.x + nx) + sx; v.y = (v.y + ny) + sy; v.z = (v.z + nz) + sz; }
+      j0 += 64;
+      if (j0 >= cnt) { ++sg; if (sg < nseg) open_segment(); }
+    }
     return v;
   };
-  float4 vnext = make_float4(far, far, far, 0.f);
-  if (nseg > 0) { open_segment(); vnext = fetch(); }
   const float reach2 = rc * rc;
-  while (sg < nseg) {
-    const float4 v = vnext;
-    j0 += 64;
-    if (j0 >= cnt) { ++sg; if (sg < nseg) open_segment(); }
-    if (sg < nseg) vnext = fetch();
+  auto handle = [&](const float4& v) {
     const float ex = fmaxf(fmaxf(ax0 - v.x, v.x - bx), 0.f), ey = fmaxf(fmaxf(ay0 - v.y, v.y - by), 0.f), ez = fmaxf(fmaxf(az0 - v.z, v.z - bz), 0.f);
     const bool in = ex * ex + ey * ey + ez * ez < reach2;
     const unsigned long long mk = __builtin_amdgcn_ballot_w64(in);
@@ -719,6 +726,18 @@ short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict
       fill -= 64;
       if (lane < fill) tile[lane] = r;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  };
+  if (nseg > 0) open_segment();
+  float4 vq[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) vq[u] = fetch_next();
+  for (int k = 0; k < nloads; k += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const float4 v = vq[u];
+      vq[u] = fetch_next();
+      if (k + u < nloads) handle(v);
     }
   }
   if (fill > 0) {
@@ -797,15 +816,15 @@ int ensure_cells(nb_ctx* c, nb_mesh_state& s, int64_t n, int esz, int ncell3) {
 template <typename T, typename V4>
 int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z, const T* m, int64_t n, double L, int nc,
                 double alpha, double rcut, double eps2, double G, T* ax, T* ay, T* az) {
-  // fp32 and enough particles: the W-sink tile kernel on cells of edge >= r_cut / div, div = 3 or 2 — the finest with >= 4 particles per
+  // fp32 and >= 16 384 particles: the W-sink tile kernel on cells of edge >= r_cut / div, div = 3 or 2 — the finest with >= 4 particles per
   // cell on average (emptier cells mean many short segments per blob: measured slower than the 64-sink kernel below). NB_SR_TILES=0/1
   // forces it off/on, NB_SR_W (8 | 16) and NB_SR_DIV (1..3) choose the blob width and the cell size.
   static const int tiles_env = getenv("NB_SR_TILES") ? atoi(getenv("NB_SR_TILES")) : -1;
   static const int w_env = getenv("NB_SR_W") ? atoi(getenv("NB_SR_W")) : 0, div_env = getenv("NB_SR_DIV") ? atoi(getenv("NB_SR_DIV")) : 0;
-  const int tile_w = w_env == 8 ? 8 : 16;
+  const int tile_w = (w_env == 8 || w_env == 16) ? w_env : (n < 100000 ? 8 : 16);   // small systems: more, shorter waves (32^3 farm run 0.132 -> 0.116 s)
   int reach = 0, nf = 0;
   bool use_tiles = false;
-  if (sizeof(T) == 4 && tiles_env != 0 && (tiles_env > 0 || n >= 262144)) {
+  if (sizeof(T) == 4 && tiles_env != 0 && (tiles_env > 0 || n >= 16384)) {
     const int d_hi = (div_env >= 1 && div_env <= 3) ? div_env : 3, d_lo = (div_env >= 1 && div_env <= 3) ? div_env : 2;
     for (int d = d_hi; d >= d_lo && !use_tiles; --d) {
       const int f = (int)floor((double)d * L / rcut);

@@ -182,7 +182,7 @@ def test_long_range_through_lds_bricks_matches_oracle(ngrid, interlace, dtype):
 @pytest.mark.parametrize("equal_masses", [True, False])
 @pytest.mark.parametrize("clustered", [False, True])
 def test_short_range_tile_kernel_matches_oracle(eps, equal_masses, clustered):
-    """fp32, >= 262 144 particles and >= 4 per cell of edge r_cut/3: the pair sum runs on 16-sink tiles (candidate segments from the blob's
+    """fp32, >= 16 384 particles and >= 4 per cell of edge r_cut/3: the pair sum runs on 16-sink tiles (candidate segments from the blob's
     bounding box, sources culled against it and compacted in LDS). Sampled sinks — among them the ones next to the box faces, whose
     partners are periodic images — against the NumPy oracle, for the four instantiations of the kernel."""
     n, L, ngrid = 300000, 80.0, 48
@@ -201,10 +201,10 @@ def test_short_range_tile_kernel_matches_oracle(eps, equal_masses, clustered):
 def test_close_pair_across_a_box_face_keeps_fp32_precision():
     """Two particles 0.08 apart on either side of the face z = L, in a box of L = 80 (fp32 ulp(L) = 8e-6): the pair kernels work in
     coordinates relative to the sink blob, so the image shift is a small number and the separation keeps its precision — with a plain +-L
-    shift the force of this pair was off by 4e-5 of its size."""
+    shift the force of this pair was off by 4.3e-5 of its size."""
     L, ngrid, eps = 80.0, 48, 0.15
     rs = 1.25 * L / ngrid
-    for n in (2000, 300000):                      # the 64-sink kernel and the 16-sink tile kernel
+    for n in (2000, 30000, 300000):               # the 64-sink kernel, the 8-sink and the 16-sink tile kernel
         pos, _ = _cloud(n, L, 21)
         pos[0] = (64.74076843, 31.28139877, 79.99965668)
         pos[1] = (64.66902160, 31.25299840, 0.02958335)
@@ -212,7 +212,9 @@ def test_close_pair_across_a_box_face_keeps_fp32_precision():
         p = pos.astype(np.float32).astype(np.float64)
         got = _accel(pos, m, np.float32, L, "p3m", ngrid, eps, part="short")
         ref = mo.short_range_accel(p, m, L, rs, 4.5 * rs, eps, sinks=np.array([0, 1]))
-        assert np.abs(got[:2] - ref).max() < 4e-6 * np.abs(ref).max(), n
+        # the 64-sink kernel subtracts L from the coordinate next to the far face (exact); the tile kernels round the source once at the
+        # scale of the blob's extent (a few units here, not L)
+        assert np.abs(got[:2] - ref).max() < (4e-6 if n == 2000 else 1e-5) * np.abs(ref).max(), n
 
 
 @pytest.mark.parametrize("seed", range(8))
