@@ -22,11 +22,15 @@
 //   inverse    3 x hipFFT Z2Z backward
 //   gather     CIC interpolation of both lattices to the particles, averaged; n >= 1e5: the six force fields of a brick
 //              staged in a 48 KB LDS tile                                                           [HBM gather bound]
-// Short range: particles are sorted (rocPRIM radix sort) by cell of side >= r_cut, then by Morton sub-cell; one 128-thread
-// block per chunk of 128 consecutive particles of a row of cells walks the neighbouring rows, source tiles staged through
-// LDS and read back as wave-uniform broadcasts (the accel_f32.hip pattern); a wave-level vote skips the erfc/exp
-// arithmetic for sources out of reach of all 64 sinks; the periodic image is a per-segment shift, not a per-pair
-// minimum image.                                                                                    [VALU bound]
+// Short range: particles are sorted (rocPRIM radix sort) by cell, then by Morton sub-cell; cells are contiguous in memory along z,
+// so the neighbourhood of a group of sinks is a handful of contiguous segments, one per neighbouring ROW of cells, and the
+// periodic image is a per-segment shift, not a per-pair minimum image.                              [VALU bound]
+//   fp32, >= 16 384 particles, >= 4 per cell: cells of side >= r_cut/3, one wave per 16 (8) consecutive sinks replicated over 4 (8)
+//              source slots; segments chosen from the blob's bounding box, every loaded source tested against the box and the
+//              survivors compacted in LDS; 64-pair steps with a wave vote (short_range_tile_kernel)
+//   otherwise (fp64, sparse cells, small systems): cells of side >= r_cut, one wave per chunk of 128 consecutive particles
+//              of a row (two 64-sink sets per lane), source tiles read back from LDS as wave-uniform broadcasts (the
+//              accel_f32.hip pattern), a wave vote per source and sink set (short_range_kernel)
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
 #include <cmath>
