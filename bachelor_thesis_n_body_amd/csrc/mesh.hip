@@ -58,6 +58,8 @@ struct nb_mesh_state {
   size_t tmp_bytes = 0;
   float* table = nullptr;            // long-range complement of the pair force tabulated in r^2 (fp32 short-range kernel)
   double table_alpha = 0.0, table_rcut = 0.0;
+  float2* ltab = nullptr;            // tile kernel: the whole pair factor on a grid logarithmic in x = r^2 + eps^2 (LT_N entries)
+  double ltab_alpha = 0.0, ltab_rcut = 0.0, ltab_eps2 = -1.0;
 };
 
 namespace {
@@ -565,6 +567,39 @@ sr_reduce_kernel(const double* __restrict__ part, int ny, const uint32_t* __rest
 // >= r_cut / 3 and the candidates are picked per neighbouring ROW of cells (fixed cx, cy: contiguous in memory along z) from the blob's
 // own bounding box: a row is skipped when its column is out of reach, and of the others only the z-interval within sqrt(r_cut^2 - d_xy^2)
 // of the box is walked — ~2 200 candidates per 8-sink blob instead of 5 000 per 64-sink one, at no per-candidate test or vote.
+// The tile kernel reads the WHOLE pair factor  g(x) = x^{-3/2} - T(x - eps^2),  x = r^2 + eps^2,  from a table logarithmic in x: interval i
+// is the set of floats whose bits >> LT_SHIFT equal base + i (2^LT_M intervals per octave, LT_OCT octaves below x_cut = r_cut^2 + eps^2), and
+// stores (a, b) with g ~ a + b x on it — the index is two integer instructions on the bits of x, the value one fma: no v_rsq_f32, no
+// fraction. Chord through the end points, lowered by 2/3 of its mid-point error (zero mean error over the interval): 2^8 intervals per
+// octave give |error| <= 4.8e-6 of the Newtonian term, +-1e-6 of a summed short-range force. x below the table (closer than r_cut / 64,
+// the particle itself) takes a branch with v_rsq_f32 and the series of T.
+constexpr int LT_M = 8, LT_SHIFT = 23 - LT_M, LT_OCT = 12, LT_N = LT_OCT << LT_M;
+
+__device__ inline double sr_pair_factor(double x, double eps2, double alpha) {
+  const double s = x > eps2 ? x - eps2 : 0.0;
+  double t = 4.0 * alpha * alpha * alpha / (3.0 * 1.7724538509055159);
+  if (s > 1e-14 / (alpha * alpha)) { const double r = sqrt(s), u = alpha * r; t = (erf(u) - 2.0 * u / 1.7724538509055159 * exp(-u * u)) / (s * r); }
+  return 1.0 / (x * sqrt(x)) - t;
+}
+
+__global__ void __launch_bounds__(256)
+sr_logtable_kernel(float2* __restrict__ tab, int base, double alpha, double eps2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= LT_N) return;
+  const double x0 = (double)__uint_as_float((uint32_t)(base + i) << LT_SHIFT), x1 = (double)__uint_as_float((uint32_t)(base + i + 1) << LT_SHIFT);
+  const double g0 = sr_pair_factor(x0, eps2, alpha), g1 = sr_pair_factor(x1, eps2, alpha);
+  const double b = (g1 - g0) / (x1 - x0), xm = 0.5 * (x0 + x1);
+  const double a = g0 - b * x0 + (2.0 / 3.0) * (sr_pair_factor(xm, eps2, alpha) - (g0 + b * (xm - x0)));
+  tab[i] = make_float2((float)a, (float)b);
+}
+
+// v of the lane E places further on in this lane's row of 16 (rotation within the row): a DPP modifier on the consuming instruction
+template <int E>
+__device__ inline float dpp_row_ror(float v) {
+  if constexpr (E == 0) return v;
+  else return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + E, 0xf, 0xf, false));
+}
+
 // chunk k of the tile kernel -> (row, first sorted particle, last sorted particle): one binary search per chunk here, in a streaming
 // kernel, instead of 13 dependent loads at the start of every (short-lived) wave
 __global__ void __launch_bounds__(256)
@@ -583,14 +618,15 @@ template <int W, bool SOFT, bool UNI>
 __global__ void __launch_bounds__(64 * SRT)
 short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict__ cell_start, const int4* __restrict__ chunk_info,
                         int total, int nf, int reach, float L, float rcut, float eps2, double G,
-                        const uint32_t* __restrict__ idx_s, const float* __restrict__ table, float* __restrict__ ax,
-                        float* __restrict__ ay, float* __restrict__ az, const unsigned char* __restrict__ rung, int min_rung) {
-  constexpr int S = 64 / W;                    // sources in flight per step
+                        const uint32_t* __restrict__ idx_s, const float2* __restrict__ ltab, int lbase, float t0c, float t1c,
+                        float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, const unsigned char* __restrict__ rung,
+                        int min_rung) {
   constexpr int MAXSEG = 49 * 3 + 1;           // (2*3+1)^2 neighbouring rows x up to three periodic images along z
   __shared__ float4 tiles[SRT][128];            // sources in reach of the blob: 64 being consumed + up to 63 waiting
-  __shared__ float2 tab2[TABN + 1];             // T(r^2) ~ tab2[i].x + tab2[i].y * t on t = r^2 * TABN / r_cut^2 in [i, i+1): index, one LDS read, one fma
-  __shared__ int seg_b0[SRT][MAXSEG], seg_cnt[SRT][MAXSEG], seg_img[SRT][MAXSEG];   // img: periodic image, 2 bits per axis (0: -L, 1: 0, 2: +L)
-  for (int t = threadIdx.x; t <= TABN; t += 64 * SRT) { const float t0 = table[t], d = table[t + 1] - t0; tab2[t] = make_float2(t0 - d * (float)t, d); }
+  __shared__ float2 ltb[LT_N];                  // pair factor ~ ltb[i].x + ltb[i].y * x on the floats x with bits >> LT_SHIFT == lbase + i
+  // segment: first particle; count (26 bits) | periodic image << 26 (2 bits per axis: 0: -L, 1: 0, 2: +L)
+  __shared__ int seg_b0[SRT][MAXSEG], seg_ci[SRT][MAXSEG];
+  for (int t = threadIdx.x; t < LT_N; t += 64 * SRT) ltb[t] = ltab[t];
   __syncthreads();                              // the only block-wide step
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float4* tile = tiles[wv];
@@ -648,12 +684,13 @@ short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict
     const unsigned long long mk = __builtin_amdgcn_ballot_w64(nmine > k);
     if (nmine > k) {
       const int pos = nseg + __popcll(mk & ((1ull << lane) - 1ull));
-      seg_b0[wv][pos] = sb0[k]; seg_cnt[wv][pos] = scn[k]; seg_img[wv][pos] = simg[k];
+      seg_b0[wv][pos] = sb0[k]; seg_ci[wv][pos] = scn[k] | (simg[k] << 26);
     }
     nseg += __popcll(mk);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  const float rcut2 = rcut * rcut, tscale = (float)TABN / rcut2;
+  const float xcut = rcut * rcut + eps2;        // the cut-off on x = r^2 + eps^2
+  const float xlo = __uint_as_float((uint32_t)lbase << LT_SHIFT);
   const float far = 1e18f;
   // From here on coordinates are relative to the low corner of the blob's box: a source that reaches the sinks through a periodic image
   // is shifted by (image - corner), a small number, instead of by +-L — in fp32 a close pair across a box face keeps the precision it
@@ -665,28 +702,37 @@ short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict
   const float4 mel = make_float4(me.x - ox, me.y - oy, me.z - oz, me.w);
   const float ax0 = lox - ox, ay0 = loy - oy, az0 = loz - oz, bx = hix - ox, by = hiy - oy, bz = hiz - oz;   // the box in those coordinates
   double tx = 0.0, ty = 0.0, tz = 0.0;
-  // `steps` steps over buf[0 .. steps*S): S sources per step, one per slot
-  auto consume = [&](int steps) {
+  // 64 buffered sources against the W sinks, no LDS traffic per pair: lane l takes source l into registers (one conflict-free
+  // ds_read_b128), so each row of 16 lanes holds 16 sources, and in step e a lane meets the source of the lane e places further in its
+  // row (DPP row rotation folded into the subtractions). W steps: lanes l and l + W of a row hold the same sink and between them meet all
+  // 16 sources of the row once. (With one ds_read_b96 per pair step the four SIMDs of a CU kept its LDS 70 % busy — the tile reads and
+  // the random table reads together — and the kernel was LDS bound, not VALU bound.)
+  auto consume64 = [&]() {
+    const float4 src = tile[lane];
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    for (int e = 0; e < steps; e += 2) {                     // two steps per trip; an odd tail reads padding
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const float4 q = tile[(e + u) * S + slot];
-        const float dx = q.x - mel.x, dy = q.y - mel.y, dz = q.z - mel.z;
-        const float r2 = dx * dx + dy * dy + dz * dz;
-        // wave-uniform: no pair of this step in reach (a third of the steps; measured without the vote — straight-line code, LDS reads of
-        // neighbouring steps overlapped: 256^3 23.2 -> 37.8 ms, 32^3 farm run 0.116 -> 0.124 s)
-        if (__builtin_amdgcn_ballot_w64(r2 < rcut2) == 0) continue;
-        const float t = r2 * tscale;                             // lanes beyond the cut-off read anything (or nothing: LDS reads out of
-        const float2 ab = tab2[(int)t];                          // range return 0) and are masked below
-        const float sinv = __builtin_amdgcn_rsqf(r2 + eps2);
-        const float soft = (SOFT || r2 > 0.f) ? sinv * sinv * sinv : 0.f;
-        float f = soft - fmaf(ab.y, t, ab.x);
-        if (!UNI) f *= q.w;
-        f = r2 < rcut2 ? f : 0.f;
-        fx = fmaf(f, dx, fx); fy = fmaf(f, dy, fy); fz = fmaf(f, dz, fz);
-      }
+#define NB_TILE_STEP(E)                                                                                                         \
+    if constexpr ((E) < W) {                                                                                                    \
+      const float qx = dpp_row_ror<(E)>(src.x), qy = dpp_row_ror<(E)>(src.y), qz = dpp_row_ror<(E)>(src.z);                    \
+      const float dx = qx - mel.x, dy = qy - mel.y, dz = qz - mel.z;                                                            \
+      const float x = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));                                                           \
+      if (__builtin_amdgcn_ballot_w64(x < xcut) != 0) {          /* wave-uniform: some pair of this step is in reach */        \
+        /* lanes beyond the cut-off read anything (or nothing: LDS reads out of range return 0) and are masked below */         \
+        const float2 ab = ltb[(int)(__float_as_uint(x) >> LT_SHIFT) - lbase];                                                   \
+        float f = fmaf(ab.y, x, ab.x);                                                                                          \
+        if (__builtin_amdgcn_ballot_w64(x < xlo) != 0) {         /* closer than r_cut/64 (the particle itself, eps -> 0): rare */ \
+          asm volatile("" ::: "memory");                         /* a real branch: not to be speculated into every step */      \
+          const float y = __builtin_amdgcn_rsqf(x);                                                                             \
+          const float g = ((SOFT || x > eps2) ? y * y * y : 0.f) - t0c * fmaf(t1c, x - eps2, 1.f);   /* T(s) = T(0) (1 - 3/5 alpha^2 s + ...) */ \
+          f = x < xlo ? g : f;                                                                                                  \
+        }                                                                                                                       \
+        if (!UNI) f *= dpp_row_ror<(E)>(src.w);                                                                                 \
+        f = x < xcut ? f : 0.f;                                                                                                 \
+        fx = fmaf(f, dx, fx); fy = fmaf(f, dy, fy); fz = fmaf(f, dz, fz);                                                       \
+      }                                                                                                                         \
     }
+    NB_TILE_STEP(0) NB_TILE_STEP(1) NB_TILE_STEP(2) NB_TILE_STEP(3) NB_TILE_STEP(4) NB_TILE_STEP(5) NB_TILE_STEP(6) NB_TILE_STEP(7)
+    NB_TILE_STEP(8) NB_TILE_STEP(9) NB_TILE_STEP(10) NB_TILE_STEP(11) NB_TILE_STEP(12) NB_TILE_STEP(13) NB_TILE_STEP(14) NB_TILE_STEP(15)
+#undef NB_TILE_STEP
     tx += (double)fx; ty += (double)fy; tz += (double)fz;
   };
   // The (segment, 64-source load) walk: a scalar iterator runs PF loads ahead of the consumer, so PF global loads are in flight per wave
@@ -697,8 +743,9 @@ short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict
   int sg = 0, j0 = 0, b0 = 0, cnt = 0, fill = 0;
   float sx = 0.f, sy = 0.f, sz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
   auto open_segment = [&]() {
-    b0 = __builtin_amdgcn_readfirstlane(seg_b0[wv][sg]); cnt = __builtin_amdgcn_readfirstlane(seg_cnt[wv][sg]);
-    const int code = __builtin_amdgcn_readfirstlane(seg_img[wv][sg]);
+    b0 = __builtin_amdgcn_readfirstlane(seg_b0[wv][sg]);
+    const int ci = __builtin_amdgcn_readfirstlane(seg_ci[wv][sg]), code = (int)((unsigned)ci >> 26);
+    cnt = ci & ((1 << 26) - 1);
     // v + shift - origin in two exact steps: L is subtracted from whichever lies next to the far face (the source for a shift of -L: first
     // term; the blob's origin for +L: second term), cf. the 64-sink kernel above
     const float hx = (float)((code & 3) - 1) * L, hy = (float)(((code >> 2) & 3) - 1) * L, hz = (float)(((code >> 4) & 3) - 1) * L;
@@ -724,7 +771,7 @@ short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict
     fill += __popcll(mk);
     if (fill >= 64) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      consume(64 / S);
+      consume64();
       const float4 r = tile[64 + lane];                      // the overflow moves to the front
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       fill -= 64;
@@ -745,10 +792,9 @@ short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict
     }
   }
   if (fill > 0) {
-    const int steps = (fill + S - 1) / S, padded = ((steps + 1) & ~1) * S;
-    if (lane + fill < padded) tile[fill + lane] = make_float4(far, far, far, 0.f);   // padded - fill < 2 S <= 64
+    if (lane >= fill) tile[lane] = make_float4(far, far, far, 0.f);     // the last, partial batch: padding beyond every cut-off
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    consume(steps);
+    consume64();
   }
   // the S slots of a sink, added in a fixed order
 #pragma unroll
@@ -828,7 +874,7 @@ int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z,
   const int tile_w = (w_env == 8 || w_env == 16) ? w_env : (n < 100000 ? 8 : 16);   // small systems: more, shorter waves (32^3 farm run 0.132 -> 0.116 s)
   int reach = 0, nf = 0;
   bool use_tiles = false;
-  if (sizeof(T) == 4 && tiles_env != 0 && (tiles_env > 0 || n >= 16384)) {
+  if (sizeof(T) == 4 && tiles_env != 0 && (tiles_env > 0 || n >= 16384) && n < (1ll << 26)) {   // (a segment's count is stored in 26 bits)
     const int d_hi = (div_env >= 1 && div_env <= 3) ? div_env : 3, d_lo = (div_env >= 1 && div_env <= 3) ? div_env : 2;
     for (int d = d_hi; d >= d_lo && !use_tiles; --d) {
       const int f = (int)floor((double)d * L / rcut);
@@ -879,10 +925,20 @@ int short_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z,
       }
       chunk_info_kernel<<<(unsigned)((max_chunks + 255) / 256), 256, 0, st>>>(s.cell_start, s.chunk_off, nrows, nc, tile_w, (int)max_chunks, s.chunk_info);
       NB_HIP(c, hipGetLastError());
+      const float eps2f = (float)eps2, rcf = (float)rcut, xcut = rcf * rcf + eps2f;     // as the kernel computes it
+      uint32_t xb; memcpy(&xb, &xcut, 4);
+      const int lbase = (int)(xb >> LT_SHIFT) + 1 - LT_N;
+      if (!s.ltab || s.ltab_alpha != alpha || s.ltab_rcut != rcut || s.ltab_eps2 != eps2) {
+        if (!s.ltab) NB_HIP(c, hipMalloc((void**)&s.ltab, LT_N * sizeof(float2)));
+        sr_logtable_kernel<<<(LT_N + 255) / 256, 256, 0, st>>>(s.ltab, lbase, alpha, (double)eps2f);
+        NB_HIP(c, hipGetLastError());
+        s.ltab_alpha = alpha; s.ltab_rcut = rcut; s.ltab_eps2 = eps2;
+      }
+      const float t0c = (float)(4.0 * alpha * alpha * alpha / (3.0 * 1.7724538509055159)), t1c = (float)(-0.6 * alpha * alpha);
       const unsigned gridx = (unsigned)((max_chunks + SRT - 1) / SRT);
       const bool soft_t = eps2 > 0.0 && (float)eps2 > 1e-30f, uni_t = c->uniform_mass;
 #define NB_ST2(WW, SF, UN) short_range_tile_kernel<WW, SF, UN><<<gridx, 64 * SRT, 0, st>>>((const float4*)s.sorted, s.cell_start, s.chunk_info, (int)max_chunks, \
-    nc, reach, (float)L, (float)rcut, (float)eps2, G, s.idx_s, s.table, ax, ay, az, c->sr_rung, c->sr_min_rung)
+    nc, reach, (float)L, rcf, eps2f, G, s.idx_s, s.ltab, lbase, t0c, t1c, ax, ay, az, c->sr_rung, c->sr_min_rung)
 #define NB_ST(WW) do { if (soft_t && uni_t) NB_ST2(WW, true, true); else if (soft_t) NB_ST2(WW, true, false); else if (uni_t) NB_ST2(WW, false, true); \
                        else NB_ST2(WW, false, false); } while (0)
       if (tile_w == 16) NB_ST(16); else NB_ST(8);
@@ -1013,7 +1069,7 @@ void nb_mesh_release(nb_ctx* c) {
   for (auto& g : s.grid) if (g) (void)hipFree(g);
   if (s.have_fft) (void)hipfftDestroy(s.fft);
   for (void* p : {(void*)s.keys, (void*)s.keys_s, (void*)s.idx, (void*)s.idx_s, s.sorted, (void*)s.cell_start,
-                  (void*)s.chunk_cnt, (void*)s.chunk_off, s.tmp, (void*)s.table, (void*)s.chunk_info})
+                  (void*)s.chunk_cnt, (void*)s.chunk_off, s.tmp, (void*)s.table, (void*)s.chunk_info, (void*)s.ltab})
     if (p) (void)hipFree(p);
   delete c->mesh;
   c->mesh = nullptr;
