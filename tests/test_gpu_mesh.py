@@ -198,6 +198,30 @@ def test_short_range_tile_kernel_matches_oracle(eps, equal_masses, clustered):
     assert np.abs(got[idx] - ref).max() < 3e-5 * _scale(ref)
 
 
+@pytest.mark.parametrize("seed", range(7))
+def test_short_range_tile_kernel_random_configurations(seed):
+    """The tile kernel over its parameter space: 8- and 16-sink blobs (n below / above 100 000), cells of r_cut/3 and r_cut/2 (>= 4 particles
+    per cell decides), few cells per side (every neighbouring row a periodic image), box sizes, softenings, equal and unequal masses,
+    uniform and clustered clouds — sampled sinks against the NumPy oracle."""
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.choice([20000, 60000, 150000]))
+    L = float(rng.choice([10.0, 333.0]))
+    ngrid = int(rng.choice([18, 24, 32, 40]))     # 3 ... 7 cells of edge r_cut per side; always >= 4 particles per r_cut/2 cell
+    eps = float(rng.choice([0.0, 0.02 * L / ngrid, 0.4 * L / ngrid]))
+    if seed == 6:
+        n, L, ngrid, eps = 20000, 100.0, 40, 0.05     # 2.2 particles per r_cut/3 cell, 7.3 per r_cut/2 cell: the coarser cells
+    pos, mr = _cloud(n, L, 700 + seed, clustered=bool(seed % 2))
+    m = mr if seed % 3 else np.full(n, 1.25)
+    p = pos.astype(np.float32).astype(np.float64); mm = m.astype(np.float32).astype(np.float64)
+    rs = 1.25 * L / ngrid
+    got = _accel(pos, m, np.float32, L, "p3m", ngrid, eps, part="short")
+    near_face = np.argsort(np.minimum(p, L - p).min(1))[:32]
+    idx = np.unique(np.concatenate([rng.choice(n, 96, replace=False), near_face]))
+    ref = mo.short_range_accel(p, mm, L, rs, 4.5 * rs, eps, sinks=idx)
+    assert np.isfinite(got).all()
+    assert np.abs(got[idx] - ref).max() < 3e-5 * _scale(ref), (n, L, ngrid, eps)
+
+
 def test_close_pair_across_a_box_face_keeps_fp32_precision():
     """Two particles 0.08 apart on either side of the face z = L, in a box of L = 80 (fp32 ulp(L) = 8e-6): the pair kernels work in
     coordinates relative to the sink blob, so the image shift is a small number and the separation keeps its precision — with a plain +-L
