@@ -240,7 +240,7 @@ def run_pp(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: flo
            range_scales: float = 4.5, schedule=None):
     """Comoving periodic run on the GPU with `nsteps` steps uniform in ln a. Returns (pos, vel) at a_end.
     gravity = 'pp' (Ewald summation; dtype float32 selects the fp32 kernels, forces good to ~1e-5. Default splitting
-    alpha_L = 16.5, kmax = 19: the real-space terms have died out within a fifth of the box and are summed from cell lists;
+    alpha_L = 14.9, kmax = 17 (fp32; 16.5, 19 in fp64): the real-space terms have died out within a quarter of the box and are summed from cell lists;
     alpha_L = 6.2, kmax = 7 selects the all-pairs minimum-image real-space sum, `nb_set_periodic`),
     'pm' or 'p3m' (mesh of ngrid^3 cells, default cbrt(N) / 2 cbrt(N) as in CONCEPT) — the three solvers of
     PPPMP3M/pppmp3mplotter.py:14.
@@ -271,7 +271,10 @@ def run_pp(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: flo
         raise ValueError("gravity must be 'pp', 'pm' or 'p3m'")
     with Engine(n, dtype, device) as e:
         if gravity == "pp":
-            e.set_periodic(boxsize, alpha_L if alpha_L else 16.5, kmax if kmax else 19)
+            # the balance between the cell-list real-space sum and the reciprocal sum (tools/ewald_alpha_sweep.py, 64^3): fp32 — tile pair
+            # kernel — 14.9 / 17: 6.0 ms per evaluation (16.5 / 19: 6.8); fp64 — exact erf/exp pair factor — 16.5 / 19
+            f32 = np.dtype(dtype) == np.float32
+            e.set_periodic(boxsize, alpha_L if alpha_L else (14.9 if f32 else 16.5), kmax if kmax else (17 if f32 else 19))
         else:
             cb = round(n ** (1.0 / 3.0))
             e.set_mesh(gravity, boxsize, int(ngrid) if ngrid else (cb if gravity == "pm" else 2 * cb), scale_cells, range_scales,
