@@ -38,6 +38,7 @@ SIGNATURES = {
     "nb_rung_step": (_int, [_vp, _int, _vp, _vp, _dbl, _dbl, _dbl, _dbl, C.POINTER(_i64)]),
     "nb_last_run_used_graph": (_int, [_vp]),
     "nb_clock_probe_begin": (_int, [_int, _dbl, C.POINTER(_vp)]),
+    "nb_clock_probe_stop": (_int, [_vp, _vp]),
     "nb_clock_probe_end": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_dbl)]),
     "nb_set_state": (_int, [_vp] + [_vp] * 7),
     "nb_get_state": (_int, [_vp] + [_vp] * 7),

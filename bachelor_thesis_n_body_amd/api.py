@@ -239,12 +239,17 @@ def energy(state: State, eps: float, G: float = 1.0, dtype=None, device: int = 0
 
 class ClockProbe:
     """Sustained shader clock of one GPU over a time window (nb_clock_probe_begin / _end): start it, launch the kernels of interest,
-    then `mhz, window_ms = probe.end()`. A measurement aid for bench.py's roofline line; no counterpart in the reference."""
+    `probe.stop(stream)`, then `mhz, window_ms = probe.end()`. A measurement aid for bench.py's roofline line; no counterpart in the reference."""
 
     def __init__(self, device: int, window_ms: float):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         _lib.check(None, self._lib.nb_clock_probe_begin(int(device), float(window_ms), C.byref(self._h)), "nb_clock_probe_begin")
+
+    def stop(self, stream: int = 0) -> None:
+        """End the window when the work enqueued so far on `stream` (a hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream)
+        has finished — without this the window lasts the full `window_ms`, and a device-wide synchronisation waits for it."""
+        _lib.check(None, self._lib.nb_clock_probe_stop(self._h, C.c_void_p(int(stream))), "nb_clock_probe_stop")
 
     def end(self) -> Tuple[float, float]:
         if not self._h:

@@ -76,7 +76,8 @@ def live_traffic(args, timeout_s=150):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="nb_pmc_", dir="/tmp")
         cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, str(Path(__file__).resolve()),
-               "--steps", "1", "--warmup", "0", "--n", str(args.n), "--dtype", args.dtype, "--no-cpu-baseline", "--traffic", "none"]
+               "--steps", "1", "--warmup", "0", "--n", str(args.n), "--dtype", args.dtype, "--no-cpu-baseline", "--traffic", "none",
+               "--no-clock-probe"]        # counter collection serialises kernels: the probe wave would hold the GPU for its whole window
         if args.general_mass:
             cmd.append("--general-mass")
         try:
@@ -251,6 +252,8 @@ def main():
                     help="drive the N GPUs from THIS process through the C-ABI's multi-device context (nb_create_multi: peer pulls of the "
                          "source blocks, no torch.distributed); with --same-device all N shards sit on GPU 0 (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="do not run the sustained-clock probe beside the timed region (for runs under rocprofv3 --pmc, which serialises kernels)")
     ap.add_argument("--traffic", choices=["live", "profile", "none"], default="live",
                     help="roofline.traffic at N = 1: 'live' = measure HBM bytes per launch now with two rocprofv3 --pmc child passes (~25 s), "
                          "falling back to the committed profile; 'profile' = the committed profile's figure; 'none' = null")
@@ -307,24 +310,21 @@ def main():
             torch.cuda.synchronize()
 
     eng.accel(eps, G)                      # initial a(x): not part of a step
-    warm_step_s = None
     for _ in range(args.warmup):
-        torch.cuda.synchronize()
-        tw = time.perf_counter()
         eng.step(dt, 1, eps, G)
-        torch.cuda.synchronize()
-        tw = time.perf_counter() - tw
-        warm_step_s = tw if warm_step_s is None else min(warm_step_s, tw)
     sync()
-    # sustained shader clock of this rank's GPU over ~80 % of the timed region (one sleeping wave on a private stream, nb_clock_probe_*):
+    # sustained shader clock of this rank's GPU over the timed region (one sleeping wave on a private stream, nb_clock_probe_*; its window is
+    # ended by a word written on the compute stream behind the last step, so the synchronisation below never waits for it):
     # boxes differ by several per cent in the clock they hold under this kernel; cycles per interaction is the box-independent figure
-    clock = nb.ClockProbe(local_rank, min(5000.0, max(1.0, 0.8e3 * warm_step_s * args.steps))) if warm_step_s else None
+    clock = None if args.no_clock_probe else nb.ClockProbe(local_rank, 5000.0)
     timer.enabled = True
     if probe is not None:
         probe.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.step(dt, 1, eps, G)
+    if clock is not None:
+        clock.stop(torch.cuda.current_stream().cuda_stream)
     sync()
     elapsed = time.perf_counter() - t0
     timer.enabled = False

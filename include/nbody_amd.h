@@ -127,13 +127,16 @@ int nb_rung_step(nb_ctx* ctx, int levels, const double* kc, const double* dc, do
 int nb_last_run_used_graph(const nb_ctx* ctx);
 
 /* ---- measurement aid ("reported absolute and as a fraction of the vector-FP32 roofline") ----
- * Sustained shader clock of `device` over the next `window_ms` milliseconds (clamped to 5 s), measured by one sleeping wave on a private
+ * Sustained shader clock of `device` over the next `window_ms` milliseconds at most (clamped to 5 s), measured by one sleeping wave on a private
  * stream that reads the shader-cycle counter and the constant-rate counter at both ends of the window — start it, run the kernels of
- * interest, then nb_clock_probe_end (blocks until the window has passed; frees the handle) returns cycles per microsecond (= MHz) and the
+ * interest, nb_clock_probe_stop on their stream, then nb_clock_probe_end (blocks until the window has ended; frees the handle) returns cycles per microsecond (= MHz) and the
  * window actually covered. bench.py reports it next to roofline.frac: boxes of this pool differ by several per cent in the clock they
  * hold under the all-pairs kernel, and cycles per interaction is the box-independent figure. No counterpart in the reference. */
 typedef struct nb_clock_probe nb_clock_probe;
 int nb_clock_probe_begin(int device, double window_ms, nb_clock_probe** probe);
+/* enqueue the end of the window on `stream` (a hipStream_t; NULL = the default stream): the probe stops when the work enqueued on that stream
+ * before this call has finished, or after window_ms, whichever comes first */
+int nb_clock_probe_stop(nb_clock_probe* probe, void* stream);
 int nb_clock_probe_end(nb_clock_probe* probe, double* mhz, double* window_ms);
 
 /* ---- host-pointer surface: the drop-in compute_forces()/step()/energy() (SURVEY §8a ⊕1-⊕3) ---- */

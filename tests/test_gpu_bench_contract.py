@@ -90,11 +90,17 @@ def test_clock_probe_measures_a_plausible_shader_clock():
     with nb.Engine(n, np.float32) as e:
         e.set_state(nb.plummer_sphere(n, 0, np.float32))
         e.accel(0.01, fetch=False)
-        probe = nb.ClockProbe(0, 20.0)
+        probe = nb.ClockProbe(0, 20.0)                  # a fixed window of 20 ms
         for _ in range(6):
             e.accel(0.01, fetch=False)
         mhz, window = probe.end()
-    assert 1200.0 < mhz < 2600.0 and 20.0 <= window < 40.0
+        assert 1200.0 < mhz < 2600.0 and 20.0 <= window < 40.0
+        probe = nb.ClockProbe(0, 3000.0)                # a window ended from a stream: as long as the work before the stop, not 3 s
+        for _ in range(6):
+            e.accel(0.01, fetch=False)
+        probe.stop(0)
+        mhz, window = probe.end()
+        assert 1200.0 < mhz < 2600.0 and 1.0 < window < 1000.0
     with pytest.raises(RuntimeError):
         probe.end()
     with pytest.raises(RuntimeError):
