@@ -337,23 +337,14 @@ def power_modes(pos, boxsize: float, ngrid: int, interlace: bool = True):
     """Per-mode (|k|, P) of the CIC-deposited, window-deconvolved overdensity, optionally INTERLACED (two grids half a
     cell apart combined in k-space, which cancels the odd aliases) — CONCEPT's estimator settings in NN.param:30-41
     ('interpolation': 'CIC', 'deconvolve': True, 'interlace': True). The thesis' own estimator (Power_compare.py) does not
-    interlace; `field.power_spectrum` mirrors that one. Deposit on the GPU, FFT of the ngrid^3 field on the host."""
+    interlace; `field.power_spectrum` mirrors that one. Deposits, FFT and deconvolution on the GPU (`nbf_power_modes`: both lattices
+    through one complex FFT); oracle: oracle/field_oracle.py::power_modes."""
     from . import field
-    h = boxsize / ngrid
     with field.FieldPlan(ngrid, boxsize) as plan:
-        plan.cic(pos); plan.affine(plan.mean(), 1.0, 1.0)
-        d1 = np.fft.fftn(plan.get())
-        if interlace:
-            plan.cic(np.mod(np.asarray(pos, np.float64) - 0.5 * h, boxsize)); plan.affine(plan.mean(), 1.0, 1.0)
-            d2 = np.fft.fftn(plan.get())
-    kv = 2 * np.pi * np.fft.fftfreq(ngrid, d=h)
-    kx, ky, kz = np.meshgrid(kv, kv, kv, indexing="ij")
-    if interlace:
-        d1 = 0.5 * (d1 + np.exp(-0.5j * h * (kx + ky + kz)) * d2)
-    w = np.sinc(kv * h / (2 * np.pi))                      # CIC window per axis: sinc^2
-    W = (w[:, None, None] * w[None, :, None] * w[None, None, :]) ** 2
-    pk = np.abs(d1 / W) ** 2 * boxsize ** 3 / ngrid ** 6
-    kmag = np.sqrt(kx ** 2 + ky ** 2 + kz ** 2)
+        pk = plan.power_modes(pos, interlace)
+    kv = 2 * np.pi * np.fft.fftfreq(ngrid, d=boxsize / ngrid)
+    k2 = kv * kv
+    kmag = np.sqrt(k2[:, None, None] + k2[None, :, None] + k2[None, None, :])
     sel = kmag > 0
     return kmag[sel], pk[sel]
 

@@ -242,6 +242,48 @@ zeldovich_kernel(const double* __restrict__ psi, double* __restrict__ pos, int N
   }
 }
 
+// positions -> the same positions seen from a lattice displaced by `shift` along every axis: np.mod(pos - shift, L)
+__global__ void __launch_bounds__(256)
+shift_positions_kernel(const double* __restrict__ pos, long long n3, double shift, double L, double* __restrict__ out) {
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n3; q += (long long)gridDim.x * blockDim.x)
+    out[q] = py_mod(pos[q] - shift, L);
+}
+
+// real grid -> real (part 0) or imaginary (part 1) part of the complex grid
+__global__ void __launch_bounds__(256)
+pack_part_kernel(const double* __restrict__ g, hipfftDoubleComplex* __restrict__ c, size_t n, int part) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (part == 0) c[i] = hipfftDoubleComplex{g[i], 0.0}; else c[i].y = g[i];
+  }
+}
+
+// c = FFT(delta_1 + i delta_2): the transforms of the two real fields are separated with the Hermitian symmetry,
+// d_1(k) = (c(k) + conj c(-k)) / 2, d_2(k) = (c(k) - conj c(-k)) / (2i), combined as CONCEPT's interlacing does,
+// d = (d_1 + e^{-i h (kx+ky+kz)/2} d_2) / 2 (NN.param:30-41 'interlace': True), deconvolved with the CIC window
+// W = ((w_i w_j) w_l)^2 and squared: out(k) = |d / W|^2 * scale. interlace = 0: d = d_1 (delta_2 = 0).
+__global__ void __launch_bounds__(256)
+power_modes_kernel(const hipfftDoubleComplex* __restrict__ c, const double* __restrict__ w1d, int N, int interlace, double scale,
+                   double* __restrict__ out) {
+  const size_t cells = (size_t)N * N * N;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < cells; idx += (size_t)gridDim.x * blockDim.x) {
+    const int l = (int)(idx % N), j = (int)((idx / N) % N), i = (int)(idx / ((size_t)N * N));
+    const size_t midx = ((size_t)((N - i) % N) * N + (size_t)((N - j) % N)) * N + (size_t)((N - l) % N);
+    const hipfftDoubleComplex F = c[idx], Fm = c[midx];
+    double dr = 0.5 * (F.x + Fm.x), di = 0.5 * (F.y - Fm.y);
+    if (interlace) {
+      const double d2r = 0.5 * (F.y + Fm.y), d2i = -0.5 * (F.x - Fm.x);
+      const int fi = i < (N + 1) / 2 ? i : i - N, fj = j < (N + 1) / 2 ? j : j - N, fl = l < (N + 1) / 2 ? l : l - N;   // np.fft.fftfreq
+      double sn, cs;
+      sincos(-3.141592653589793 * (double)(fi + fj + fl) / (double)N, &sn, &cs);      // -h (kx+ky+kz) / 2
+      dr = 0.5 * (dr + (cs * d2r - sn * d2i));
+      di = 0.5 * (di + (cs * d2i + sn * d2r));
+    }
+    const double w = (w1d[i] * w1d[j]) * w1d[l], W = w * w;
+    const double qr = dr / W, qi = di / W;
+    out[idx] = (qr * qr + qi * qi) * scale;
+  }
+}
+
 inline int grid_for(size_t n) {
   size_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -440,6 +482,49 @@ int nbf_power_bins(nbf_plan* p, double scale, double* psum, int64_t* counts) {
   F_HIP(p, hipMemcpyAsync(psum, p->psum, nb * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   static_assert(sizeof(unsigned long long) == sizeof(int64_t), "count type");
   F_HIP(p, hipMemcpyAsync(counts, p->counts, nb * sizeof(int64_t), hipMemcpyDeviceToHost, p->stream));
+  F_HIP(p, hipStreamSynchronize(p->stream));
+  return NB_OK;
+}
+
+int nbf_power_modes(nbf_plan* p, const double* pos, int64_t n, int interlace, double* out) {
+  if (!p || !out || n <= 0 || !pos) return ffail(p, NB_ERR_ARG, "nbf_power_modes: NULL argument or no particles");
+  if (!p->w1d) return ffail(p, NB_ERR_STATE, "nbf_power_modes: call nbf_set_window first");
+  const double h = p->boxsize / p->ngrid;
+  // lattice 1 -> delta_1 -> real part
+  int rc = nbf_cic(p, pos, n); if (rc) return rc;
+  double mean = 0.0;
+  rc = nbf_grid_mean(p, &mean); if (rc) return rc;
+  rc = nbf_grid_affine(p, mean, 1.0, 1.0); if (rc) return rc;
+  pack_part_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->grid, p->cgrid, p->cells, 0);
+  F_HIP(p, hipGetLastError());
+  if (interlace) {   // the lattice displaced by half a cell along every axis -> delta_2 -> imaginary part
+    const size_t need = 2 * (size_t)n * 3 * sizeof(double);
+    if (need > p->pos_cap) {          // second half of the staging buffer: the displaced positions
+      F_HIP(p, hipStreamSynchronize(p->stream));
+      double* q = nullptr;
+      F_HIP(p, hipMalloc((void**)&q, need));
+      F_HIP(p, hipMemcpyAsync(q, p->pos, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+      F_HIP(p, hipStreamSynchronize(p->stream));
+      F_HIP(p, hipFree(p->pos));
+      p->pos = q; p->pos_cap = need;
+    }
+    double* pos2 = p->pos + (size_t)n * 3;
+    shift_positions_kernel<<<grid_for((size_t)n * 3), 256, 0, p->stream>>>(p->pos, (long long)n * 3, 0.5 * h, p->boxsize, pos2);
+    F_HIP(p, hipGetLastError());
+    F_HIP(p, hipMemsetAsync(p->grid, 0, p->cells * sizeof(double), p->stream));
+    cic_kernel<<<grid_for((size_t)n), 256, 0, p->stream>>>(pos2, (long long)n, h, p->ngrid, p->grid);
+    F_HIP(p, hipGetLastError());
+    rc = nbf_grid_mean(p, &mean); if (rc) return rc;
+    rc = nbf_grid_affine(p, mean, 1.0, 1.0); if (rc) return rc;
+    pack_part_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->grid, p->cgrid, p->cells, 1);
+    F_HIP(p, hipGetLastError());
+  }
+  F_FFT(p, hipfftExecZ2Z(p->fft, p->cgrid, p->cgrid, HIPFFT_FORWARD));
+  const double N3 = (double)p->cells;
+  power_modes_kernel<<<grid_for(p->cells), 256, 0, p->stream>>>(p->cgrid, p->w1d, p->ngrid, interlace ? 1 : 0,
+                                                               p->boxsize * p->boxsize * p->boxsize / (N3 * N3), p->grid);
+  F_HIP(p, hipGetLastError());
+  F_HIP(p, hipMemcpyAsync(out, p->grid, p->cells * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   F_HIP(p, hipStreamSynchronize(p->stream));
   return NB_OK;
 }

@@ -36,6 +36,7 @@ FIELD_SIGNATURES = {
     "nbf_get_grid": (_int, [_vp, _vp]),
     "nbf_set_grid": (_int, [_vp, _vp]),
     "nbf_power_bins": (_int, [_vp, _dbl, _vp, _vp]),
+    "nbf_power_modes": (_int, [_vp, _vp, _i64, _int, _vp]),
 }
 _bound = False
 
@@ -147,6 +148,16 @@ class FieldPlan:
         counts = np.empty(len(edges) - 1, np.int64)
         self._chk(self._lib.nbf_power_bins(self._p, scale, _ptr(psum), _ptr(counts)), "nbf_power_bins")
         return edges, psum, counts
+
+    def power_modes(self, positions, interlace: bool = True) -> np.ndarray:
+        """|delta_k / W|^2 L^3 / N^6 of the CIC-deposited overdensity for every mode, (N, N, N) in np.fft order; interlace: two lattices half a
+        cell apart combined in k-space (CONCEPT's estimator settings, NN.param:30-41). Deposit, FFT and deconvolution on the GPU."""
+        p = np.ascontiguousarray(positions, np.float64)
+        if p.ndim != 2 or p.shape[1] != 3:
+            raise ValueError("positions must have shape (N, 3)")
+        out = np.empty((self.ngrid,) * 3, np.float64)
+        self._chk(self._lib.nbf_power_modes(self._p, _ptr(p), p.shape[0], 1 if interlace else 0, _ptr(out)), "nbf_power_modes")
+        return out
 
     # -- the reference's per-snapshot chain (Feeder_pipe.py:174-195), one device pass --------------------
     def delta_field(self, positions, subtract_mean: bool = False) -> np.ndarray:

@@ -51,6 +51,12 @@ int nbf_set_grid(nbf_plan* plan, const double* in);
 /* psum[nedges-1], counts[nedges-1] <- histogram over all modes of |fftn(grid)|^2 * scale, binned by |k| */
 int nbf_power_bins(nbf_plan* plan, double scale, double* psum, int64_t* counts);
 
+/* |delta_k / W|^2 L^3 / N^6 for every mode of the CIC-deposited overdensity, in np.fft order (out: host, ngrid^3 doubles) — CONCEPT's
+ * estimator settings 'interpolation': 'CIC', 'deconvolve': True and, with interlace != 0, 'interlace': True (NN.param:30-41: a second
+ * lattice displaced by half a cell along every axis, combined in k-space — cancels the odd aliases). Both lattices go through ONE
+ * complex FFT. Replaces the host FFTs of the estimator behind the CONCEPT-style power-spectrum tables (PPPMP3M/PP/powerspec/powerspec_a=1.00). */
+int nbf_power_modes(nbf_plan* plan, const double* pos, int64_t n, int interlace, double* out);
+
 /* ---- Gaussian-random-field + Zel'dovich initial conditions --------------------------------
  * Replaces the O(N^3) Python triple loop createR (TheFeedingPipeline/Cosmo data create (new).py:24-47,
  * CiC/3D startbetingelser1.py:82-94) and the field synthesis around it (Cosmo data create (new).py:129-135,

@@ -148,3 +148,24 @@ def power_spectrum_plotter(positions, boxsize: float, Nmesh: int, nbins: int = 1
     sums, _ = np.histogram(kf[mask], bins=bins, weights=Pf[mask])
     nz = counts > 0
     return centers[nz], sums[nz] / counts[nz]
+
+
+def power_modes(pos, boxsize: float, ngrid: int, interlace: bool = True):
+    """Per-mode (|k|, P) of the CIC-deposited, window-deconvolved overdensity; interlace: two lattices half a cell apart combined in
+    k-space — CONCEPT's estimator settings ('interpolation': 'CIC', 'deconvolve': True, 'interlace': True: TheFeedingPipeline/NN.param:30-41),
+    the estimator behind the tables PPPMP3M/{PP,PM,P3M}/powerspec/powerspec_a=1.00. NumPy restatement (host FFTs) of what
+    `cosmo.power_modes` / `nbf_power_modes` compute on the GPU."""
+    h = boxsize / ngrid
+    pos = np.asarray(pos, np.float64)
+    d1 = np.fft.fftn(compute_delta(cic_density(pos, boxsize, ngrid)))
+    kv = 2 * np.pi * np.fft.fftfreq(ngrid, d=h)
+    kx, ky, kz = np.meshgrid(kv, kv, kv, indexing="ij")
+    if interlace:
+        d2 = np.fft.fftn(compute_delta(cic_density(np.mod(pos - 0.5 * h, boxsize), boxsize, ngrid)))
+        d1 = 0.5 * (d1 + np.exp(-0.5j * h * (kx + ky + kz)) * d2)
+    w = np.sinc(kv * h / (2 * np.pi))                      # CIC window per axis: sinc^2
+    W = (w[:, None, None] * w[None, :, None] * w[None, None, :]) ** 2
+    pk = np.abs(d1 / W) ** 2 * boxsize ** 3 / ngrid ** 6
+    kmag = np.sqrt(kx ** 2 + ky ** 2 + kz ** 2)
+    sel = kmag > 0
+    return kmag[sel], pk[sel]

@@ -119,3 +119,18 @@ def test_plotting_script_estimator_variants(nbins, grid_dtype, tol):
     k2, p2 = field.power_spectrum_plotter(pos, 500.0, 32, 100, np.float64, clip=1e-30)
     np.testing.assert_allclose(k1, k2, rtol=1e-14)
     np.testing.assert_allclose(p1, p2, rtol=1e-9)
+
+
+@pytest.mark.parametrize("ngrid,interlace", [(32, True), (32, False), (27, True), (48, True)])
+def test_power_modes_match_the_oracle(ngrid, interlace):
+    """CONCEPT's estimator settings (CIC, deconvolved, interlaced) per mode: both lattices through one complex FFT on the GPU against the NumPy
+    restatement with two host FFTs, on a reference snapshot. Odd grid sizes (27) have no Nyquist plane; 48 != the particle lattice."""
+    from bachelor_thesis_n_body_amd import cosmo
+    pos, box = sn.read_positions(str(G / "test_id0200_snapshot_a=1.00.hdf5")), sn.read_boxsize(str(G / "test_id0200_snapshot_a=1.00.hdf5"))
+    k_got, p_got = cosmo.power_modes(pos, box, ngrid, interlace=interlace)
+    k_ref, p_ref = fo.power_modes(pos, box, ngrid, interlace=interlace)
+    assert k_got.shape == k_ref.shape == (ngrid ** 3 - 1,)
+    np.testing.assert_allclose(k_got, k_ref, rtol=1e-14)
+    assert np.abs(p_got - p_ref).max() <= 1e-10 * p_ref.max()
+    big = p_ref > 1e-6 * p_ref.max()
+    np.testing.assert_allclose(p_got[big], p_ref[big], rtol=1e-7)
