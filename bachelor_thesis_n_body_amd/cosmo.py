@@ -116,24 +116,12 @@ def second_order_potential_gradient(psi, boxsize: float) -> np.ndarray:
         laplace(phi2) = sum_{i<j} [ phi1,ii phi1,jj - (phi1,ij)^2 ]
     — the source of second-order Lagrangian perturbation theory (2LPT; Bouchet et al. 1995, Scoccimarro 1998), CONCEPT's
     `realization_options = {'LPT': 2}` (Different_Sizes/Giant.param:6,70-72 carries the switch, 1LPTvs2LPT/1vs2tlptplotter.py:121-123
-    compares the two). All derivatives spectral: phi1,ij = -d_j psi_i. Host NumPy: an O(N log N) one-off next to the O(N^2) run."""
+    compares the two). All derivatives spectral: phi1,ij = -d_j psi_i; the 13 transforms run through hipFFT (`nbf_lpt2_gradient`);
+    oracle: oracle/grf_oracle.py::second_order_potential_gradient."""
+    from . import field
     psi = np.asarray(psi, np.float64)
-    n = psi.shape[1]
-    kfull = 2 * np.pi * np.fft.fftfreq(n, d=boxsize / n)
-    kv = kfull.copy()
-    if n % 2 == 0:
-        kv[n // 2] = 0.0                                   # odd derivatives of a real field have no Nyquist component
-    k = np.meshgrid(kv, kv, kv, indexing="ij")
-    pk = [np.fft.fftn(psi[i]) for i in range(3)]
-    d = lambda i, j: np.fft.ifftn(-1j * k[j] * pk[i]).real * -1.0      # phi1,ij = -d_j psi_i
-    xx, yy, zz = d(0, 0), d(1, 1), d(2, 2)
-    xy, xz, yz = d(0, 1), d(0, 2), d(1, 2)
-    src = np.fft.fftn(xx * yy + xx * zz + yy * zz - xy ** 2 - xz ** 2 - yz ** 2)
-    k2 = kfull[:, None, None] ** 2 + kfull[None, :, None] ** 2 + kfull[None, None, :] ** 2
-    k2[0, 0, 0] = 1.0
-    phi2 = -src / k2
-    phi2[0, 0, 0] = 0.0
-    return np.stack([np.fft.ifftn(1j * k[c] * phi2).real for c in range(3)])
+    with field.FieldPlan(psi.shape[1], boxsize) as plan:
+        return plan.lpt2_gradient(psi)
 
 
 def zeldovich_ics(pk_table, n_side: int, boxsize: float, cosmo: Cosmology, a_begin: float, seed_amp: int = 0,
@@ -151,7 +139,9 @@ def zeldovich_ics(pk_table, n_side: int, boxsize: float, cosmo: Cosmology, a_beg
     with grf.GRFPlan(n_side, boxsize) as plan:
         plan.set_noise(c_1, c_2, "skip_self")
         plan.set_spectrum(P)
-        psi = np.stack([plan.field(c + 1).reshape(-1) for c in range(3)], axis=1)
+        psi_grid = np.stack([plan.field(c + 1) for c in range(3)])
+        g2 = plan.lpt2_gradient(psi_grid).reshape(3, -1).T if lpt == 2 else None       # same plan: no second hipFFT plan for a 32^3 job
+        psi = psi_grid.reshape(3, -1).T
         noise_power = np.abs(plan.noise()) ** 2 if return_noise_power else None    # |R_k|^2: the realisation's power / expectation
     g = np.linspace(0, boxsize, n_side, endpoint=False)
     q = np.array(np.meshgrid(g, g, g, indexing="ij")).reshape(3, -1).T
@@ -159,7 +149,6 @@ def zeldovich_ics(pk_table, n_side: int, boxsize: float, cosmo: Cosmology, a_beg
     vel = (aH * f) * psi                                                # a^2 dx/dt with x = q + D(a) psi_1
     if lpt == 2:
         om_a = cosmo.Om / a_begin ** 3 / float(cosmo.E(a_begin)) ** 2
-        g2 = second_order_potential_gradient(psi.T.reshape(3, n_side, n_side, n_side), boxsize).reshape(3, -1).T
         psi2 = (-3.0 / 7.0) * om_a ** (-1.0 / 143.0) * g2              # psi already carries D1, so grad(phi2) carries D1^2
         vel = vel + (aH * 2.0 * om_a ** (6.0 / 11.0)) * psi2
         psi = psi + psi2

@@ -242,6 +242,48 @@ zeldovich_kernel(const double* __restrict__ psi, double* __restrict__ pos, int N
   }
 }
 
+// np.fft.fftfreq index of grid index i; odd derivatives of a real field have no Nyquist component (nyq0: that index -> 0)
+__device__ inline int fft_freq(int i, int N, bool nyq0) {
+  if (nyq0 && N % 2 == 0 && i == N / 2) return 0;
+  return i < (N + 1) / 2 ? i : i - N;
+}
+
+// out(k) = sign * i * k_axis * in(k)     (k_axis = 2 pi f / L, Nyquist component dropped)
+__global__ void __launch_bounds__(256)
+ik_multiply_kernel(const hipfftDoubleComplex* __restrict__ in, hipfftDoubleComplex* __restrict__ out, int N, double twopi_over_L,
+                   int axis, double sign) {
+  const size_t n = (size_t)N * N * N;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c[3] = {(int)(idx / ((size_t)N * N)), (int)((idx / N) % N), (int)(idx % N)};
+    const double k = sign * twopi_over_L * (double)fft_freq(c[axis], N, true);
+    const hipfftDoubleComplex v = in[idx];
+    out[idx] = hipfftDoubleComplex{-k * v.y, k * v.x};
+  }
+}
+
+// phi2(k) = -src(k) / k^2 (all components of k, Nyquist included), phi2(0) = 0; in place
+__global__ void __launch_bounds__(256)
+inverse_laplace_kernel(hipfftDoubleComplex* __restrict__ c, int N, double twopi_over_L) {
+  const size_t n = (size_t)N * N * N;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const double kx = twopi_over_L * fft_freq((int)(idx / ((size_t)N * N)), N, false), ky = twopi_over_L * fft_freq((int)((idx / N) % N), N, false),
+                 kz = twopi_over_L * fft_freq((int)(idx % N), N, false);
+    const double k2 = kx * kx + ky * ky + kz * kz;
+    if (idx == 0) c[idx] = hipfftDoubleComplex{0.0, 0.0};
+    else c[idx] = hipfftDoubleComplex{-c[idx].x / k2, -c[idx].y / k2};
+  }
+}
+
+// mode 0: s = a*b + a*c + b*c;  mode 1: s -= a*a
+__global__ void __launch_bounds__(256)
+lpt2_source_kernel(double* __restrict__ s, const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ c, size_t n,
+                   int mode) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (mode == 0) s[i] = a[i] * b[i] + a[i] * c[i] + b[i] * c[i];
+    else s[i] = s[i] - a[i] * a[i];
+  }
+}
+
 // positions -> the same positions seen from a lattice displaced by `shift` along every axis: np.mod(pos - shift, L)
 __global__ void __launch_bounds__(256)
 shift_positions_kernel(const double* __restrict__ pos, long long n3, double shift, double L, double* __restrict__ out) {
@@ -526,6 +568,60 @@ int nbf_power_modes(nbf_plan* p, const double* pos, int64_t n, int interlace, do
   F_HIP(p, hipGetLastError());
   F_HIP(p, hipMemcpyAsync(out, p->grid, p->cells * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   F_HIP(p, hipStreamSynchronize(p->stream));
+  return NB_OK;
+}
+
+int nbf_lpt2_gradient(nbf_plan* p, const double* psi, double* out) {
+  if (!p || !psi || !out) return ffail(p, NB_ERR_ARG, "nbf_lpt2_gradient: NULL argument");
+  int rc = use_dev(p); if (rc) return rc;
+  const size_t n = p->cells, rb = n * sizeof(double), cb = n * sizeof(hipfftDoubleComplex);
+  const int N = p->ngrid;
+  const double tpl = 2.0 * 3.141592653589793 / p->boxsize, inv = 1.0 / (double)n;
+  hipfftDoubleComplex* pk[3] = {nullptr, nullptr, nullptr};
+  double* diag[3] = {nullptr, nullptr, nullptr};
+  double* src = nullptr;
+  auto release = [&]() { for (auto& q : pk) if (q) (void)hipFree(q); for (auto& q : diag) if (q) (void)hipFree(q); if (src) (void)hipFree(src); };
+#define L_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { release(); \
+    return ffail(p, NB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
+#define L_FFT(call) do { hipfftResult r_ = (call); if (r_ != HIPFFT_SUCCESS) { release(); \
+    return ffail(p, NB_ERR_HIP, std::string(#call) + ": hipfft error " + std::to_string((int)r_)); } } while (0)
+  for (int i = 0; i < 3; ++i) { L_HIP(hipMalloc((void**)&pk[i], cb)); L_HIP(hipMalloc((void**)&diag[i], rb)); }
+  L_HIP(hipMalloc((void**)&src, rb));
+  const int g = grid_for(n);
+  for (int i = 0; i < 3; ++i) {                     // psi_i(k)
+    L_HIP(hipMemcpyAsync(p->grid, psi + (size_t)i * n, rb, hipMemcpyHostToDevice, p->stream));
+    r2c_kernel<<<g, 256, 0, p->stream>>>(p->grid, pk[i], n);
+    L_FFT(hipfftExecZ2Z(p->fft, pk[i], pk[i], HIPFFT_FORWARD));
+  }
+  // phi1,ij = -d_j psi_i = real(ifft(-(-i k_j) psi_i(k))) ... as the NumPy restatement: ifftn(-1j k_j psi_i).real * -1
+  auto second = [&](int i, int j, double* dst) -> int {
+    ik_multiply_kernel<<<g, 256, 0, p->stream>>>(pk[i], p->cgrid, N, tpl, j, -1.0);
+    F_FFT(p, hipfftExecZ2Z(p->fft, p->cgrid, p->cgrid, HIPFFT_BACKWARD));
+    c2r_kernel<<<g, 256, 0, p->stream>>>(p->cgrid, dst, n, -inv);
+    return NB_OK;
+  };
+  for (int i = 0; i < 3; ++i) { rc = second(i, i, diag[i]); if (rc) { release(); return rc; } }
+  lpt2_source_kernel<<<g, 256, 0, p->stream>>>(src, diag[0], diag[1], diag[2], n, 0);
+  const int off[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+  for (int q = 0; q < 3; ++q) {
+    rc = second(off[q][0], off[q][1], p->grid); if (rc) { release(); return rc; }
+    lpt2_source_kernel<<<g, 256, 0, p->stream>>>(src, p->grid, nullptr, nullptr, n, 1);
+  }
+  L_HIP(hipGetLastError());
+  r2c_kernel<<<g, 256, 0, p->stream>>>(src, pk[0], n);
+  L_FFT(hipfftExecZ2Z(p->fft, pk[0], pk[0], HIPFFT_FORWARD));
+  inverse_laplace_kernel<<<g, 256, 0, p->stream>>>(pk[0], N, tpl);
+  for (int c = 0; c < 3; ++c) {                     // grad(phi2)_c = real(ifft(i k_c phi2(k)))
+    ik_multiply_kernel<<<g, 256, 0, p->stream>>>(pk[0], p->cgrid, N, tpl, c, 1.0);
+    L_FFT(hipfftExecZ2Z(p->fft, p->cgrid, p->cgrid, HIPFFT_BACKWARD));
+    c2r_kernel<<<g, 256, 0, p->stream>>>(p->cgrid, p->grid, n, inv);
+    L_HIP(hipGetLastError());
+    L_HIP(hipMemcpyAsync(out + (size_t)c * n, p->grid, rb, hipMemcpyDeviceToHost, p->stream));
+    L_HIP(hipStreamSynchronize(p->stream));
+  }
+#undef L_HIP
+#undef L_FFT
+  release();
   return NB_OK;
 }
 

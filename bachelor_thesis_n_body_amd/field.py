@@ -37,6 +37,7 @@ FIELD_SIGNATURES = {
     "nbf_set_grid": (_int, [_vp, _vp]),
     "nbf_power_bins": (_int, [_vp, _dbl, _vp, _vp]),
     "nbf_power_modes": (_int, [_vp, _vp, _i64, _int, _vp]),
+    "nbf_lpt2_gradient": (_int, [_vp, _vp, _vp]),
 }
 _bound = False
 
@@ -157,6 +158,15 @@ class FieldPlan:
             raise ValueError("positions must have shape (N, 3)")
         out = np.empty((self.ngrid,) * 3, np.float64)
         self._chk(self._lib.nbf_power_modes(self._p, _ptr(p), p.shape[0], 1 if interlace else 0, _ptr(out)), "nbf_power_modes")
+        return out
+
+    def lpt2_gradient(self, psi) -> np.ndarray:
+        """grad(phi2) of 2LPT from the first-order displacement psi (3, N, N, N): 13 spectral transforms on the GPU (nbf_lpt2_gradient)."""
+        a = np.ascontiguousarray(psi, np.float64)
+        if a.shape != (3,) + (self.ngrid,) * 3:
+            raise ValueError(f"psi must have shape {(3,) + (self.ngrid,) * 3}")
+        out = np.empty_like(a)
+        self._chk(self._lib.nbf_lpt2_gradient(self._p, _ptr(a), _ptr(out)), "nbf_lpt2_gradient")
         return out
 
     # -- the reference's per-snapshot chain (Feeder_pipe.py:174-195), one device pass --------------------

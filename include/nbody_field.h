@@ -57,6 +57,11 @@ int nbf_power_bins(nbf_plan* plan, double scale, double* psum, int64_t* counts);
  * complex FFT. Replaces the host FFTs of the estimator behind the CONCEPT-style power-spectrum tables (PPPMP3M/PP/powerspec/powerspec_a=1.00). */
 int nbf_power_modes(nbf_plan* plan, const double* pos, int64_t n, int interlace, double* out);
 
+/* grad(phi2) of second-order Lagrangian perturbation theory from the first-order displacement psi = -grad(phi1) (psi, out: host, [3][ngrid^3]):
+ * laplace(phi2) = sum_{i<j} [ phi1,ii phi1,jj - (phi1,ij)^2 ], all derivatives spectral — CONCEPT's `realization_options = {'LPT': 2}`
+ * (Different_Sizes/Giant.param:6,70-72; 1LPTvs2LPT/1vs2tlptplotter.py:121-123 compares the two orders). 13 hipFFT transforms. */
+int nbf_lpt2_gradient(nbf_plan* plan, const double* psi, double* out);
+
 /* ---- Gaussian-random-field + Zel'dovich initial conditions --------------------------------
  * Replaces the O(N^3) Python triple loop createR (TheFeedingPipeline/Cosmo data create (new).py:24-47,
  * CiC/3D startbetingelser1.py:82-94) and the field synthesis around it (Cosmo data create (new).py:129-135,

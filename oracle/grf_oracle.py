@@ -91,3 +91,28 @@ def zeldovich_particles(P_k_grid: np.ndarray, R: np.ndarray, L: float) -> np.nda
     particles += np.column_stack((px.reshape(-1), py.reshape(-1), pz.reshape(-1)))
     particles %= L
     return particles
+
+
+def second_order_potential_gradient(psi, boxsize: float) -> np.ndarray:
+    """grad(phi2) on the lattice from the first-order displacement psi = -grad(phi1) (array (3, n, n, n)), where
+        laplace(phi2) = sum_{i<j} [ phi1,ii phi1,jj - (phi1,ij)^2 ]
+    — the source of second-order Lagrangian perturbation theory (2LPT; Bouchet et al. 1995, Scoccimarro 1998), CONCEPT's
+    `realization_options = {'LPT': 2}` (Different_Sizes/Giant.param:6,70-72 carries the switch, 1LPTvs2LPT/1vs2tlptplotter.py:121-123
+    compares the two). All derivatives spectral: phi1,ij = -d_j psi_i. NumPy restatement of what `nbf_lpt2_gradient` computes with hipFFT."""
+    psi = np.asarray(psi, np.float64)
+    n = psi.shape[1]
+    kfull = 2 * np.pi * np.fft.fftfreq(n, d=boxsize / n)
+    kv = kfull.copy()
+    if n % 2 == 0:
+        kv[n // 2] = 0.0                                   # odd derivatives of a real field have no Nyquist component
+    k = np.meshgrid(kv, kv, kv, indexing="ij")
+    pk = [np.fft.fftn(psi[i]) for i in range(3)]
+    d = lambda i, j: np.fft.ifftn(-1j * k[j] * pk[i]).real * -1.0      # phi1,ij = -d_j psi_i
+    xx, yy, zz = d(0, 0), d(1, 1), d(2, 2)
+    xy, xz, yz = d(0, 1), d(0, 2), d(1, 2)
+    src = np.fft.fftn(xx * yy + xx * zz + yy * zz - xy ** 2 - xz ** 2 - yz ** 2)
+    k2 = kfull[:, None, None] ** 2 + kfull[None, :, None] ** 2 + kfull[None, None, :] ** 2
+    k2[0, 0, 0] = 1.0
+    phi2 = -src / k2
+    phi2[0, 0, 0] = 0.0
+    return np.stack([np.fft.ifftn(1j * k[c] * phi2).real for c in range(3)])
