@@ -558,15 +558,7 @@ sr_reduce_kernel(const double* __restrict__ part, int ny, const uint32_t* __rest
   ax[o] += (T)(G * sx); ay[o] += (T)(G * sy); az[o] += (T)(G * sz);
 }
 
-// ---- fp32 pair kernel on W-sink tiles (round 2) ----
-// The wave above tests every particle of 27 cells of edge >= r_cut against a 64-sink blob: at one particle per mesh cell and r_cut = 5.6
-// cells that is ~5 000 candidates for the ~740 partners a sink really has, and only 37 % of the lanes of a passing candidate do useful
-// work — a 64-particle blob plus its reach fills the 3^3 block whatever the sub-cell order. Here a wave owns only W (8 or 16) consecutive
-// sorted sinks — a blob a fraction of r_cut wide — and 64/W sources are in flight per step (lane = sink + W * slot: the W sinks are
-// replicated over the slots, slot t takes source e*S + t of the staged tile), so a step is still 64 pairs. The cells have edge
-// >= r_cut / 3 and the candidates are picked per neighbouring ROW of cells (fixed cx, cy: contiguous in memory along z) from the blob's
-// own bounding box: a row is skipped when its column is out of reach, and of the others only the z-interval within sqrt(r_cut^2 - d_xy^2)
-// of the box is walked — ~2 200 candidates per 8-sink blob instead of 5 000 per 64-sink one, at no per-candidate test or vote.
+// ---- fp32 pair kernel on W-sink tiles (round 2): its table, its chunk list, the kernel ----
 // The tile kernel reads the WHOLE pair factor  g(x) = x^{-3/2} - T(x - eps^2),  x = r^2 + eps^2,  from a table logarithmic in x: interval i
 // is the set of floats whose bits >> LT_SHIFT equal base + i (2^LT_M intervals per octave, LT_OCT octaves below x_cut = r_cut^2 + eps^2), and
 // stores (a, b) with g ~ a + b x on it — the index is two integer instructions on the bits of x, the value one fma: no v_rsq_f32, no
@@ -614,6 +606,19 @@ chunk_info_kernel(const int* __restrict__ cell_start, const int* __restrict__ ch
   info[k] = make_int4(lo, i0, min(cell_start[(lo + 1) * nf], i0 + W) - 1, 0);
 }
 
+// The 64-sink wave above tests every particle of 27 cells of edge >= r_cut against its blob: at one particle per mesh cell and r_cut = 5.6
+// cells that is ~5 000 candidates for the ~740 partners a sink really has, and only 37 % of the lanes of a passing candidate do useful
+// work — a 64-particle blob plus its reach fills the 3^3 block whatever the sub-cell order. Here a wave owns only W (8 or 16) consecutive
+// sorted sinks of a row — a blob a fraction of r_cut wide, every lane l holding sink l % W.
+//   candidates  cells of edge >= r_cut / 3 (or / 2); per neighbouring ROW of cells (fixed cx, cy: contiguous in memory along z) one
+//               segment, chosen from the blob's bounding box: a row whose column is out of reach is dropped, of the others only the
+//               z-interval within sqrt(r_cut^2 - d_xy^2) of the box is loaded (<= 49 rows x 3 periodic images; the lanes build the list
+//               in LDS) — ~2 600 candidates per 16-sink blob instead of 5 000 per 64-sink one
+//   culling     every loaded source is tested against the box (a quarter of an instruction per candidate and lane); those in reach are
+//               appended, compacted, to an LDS buffer; four 64-source loads are in flight
+//   pair steps  64 buffered sources at a time: lane l takes source l into registers and in step e meets the source of the lane e places
+//               further on in its row of 16 (DPP row rotation) — W steps of 64 pairs, no LDS access per pair but the table read; a wave
+//               vote ends the steps without a pair in reach; the pair factor is one fma on a log-spaced table entry
 template <int W, bool SOFT, bool UNI>
 __global__ void __launch_bounds__(64 * SRT)
 short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict__ cell_start, const int4* __restrict__ chunk_info,
@@ -636,13 +641,13 @@ short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict
   const int row = ci.x, i_first = ci.y, i_last = ci.z;
   if (row < 0) return;
   const int cx = row / nf, cy = row % nf;
-  const int sk = lane & (W - 1), slot = lane / W;
+  const int sk = lane & (W - 1), slot = lane / W;      // sink of this lane; slot 0 stores the result
   const float4 me = sorted[min(i_first + sk, i_last)];   // padding sinks repeat the last one: inside the box, never stored
   if (rung) {
     const int i = i_first + sk;
     if (__builtin_amdgcn_ballot_w64(i <= i_last && rung[idx_s[i]] >= min_rung) == 0) return;
   }
-  // bounding box of the blob (every slot holds all W sinks)
+  // bounding box of the blob (every group of W lanes holds all W sinks)
   float lox = me.x, loy = me.y, loz = me.z, hix = me.x, hiy = me.y, hiz = me.z;
 #pragma unroll
   for (int o = 1; o < W; o <<= 1) {
@@ -796,7 +801,7 @@ short_range_tile_kernel(const float4* __restrict__ sorted, const int* __restrict
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     consume64();
   }
-  // the S slots of a sink, added in a fixed order
+  // the 64 / W lanes that hold the same sink, added in a fixed order
 #pragma unroll
   for (int o = W; o < 64; o <<= 1) { tx += __shfl_xor(tx, o); ty += __shfl_xor(ty, o); tz += __shfl_xor(tz, o); }
   const int i = i_first + sk;
