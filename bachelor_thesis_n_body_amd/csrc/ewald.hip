@@ -183,12 +183,24 @@ ewald_recip_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __
 // The half-space table is ordered (a, b, c) with c innermost, so the k-vectors of one (a, b) form a contiguous ROW whose members
 // differ by the constant step dk = 2 pi / L along z: e^{i k.x} of the whole row follows from ONE sincos of the row's first phase
 // and ONE sincos of dk z per particle by complex rotation (4 fma per k-vector instead of an fp64 sincos).
-constexpr int ROWC = 32;        // k-vectors per pass of a row (rows of kmax <= 15 have <= 31)
+constexpr int ROWC = 36;        // k-vectors per pass of a row: a full row of kmax = 17 (fp32 contexts' default split) has 35 — one pass
+
+// (cos, sin)(dk z_j): the step of the complex rotation along a row of k-vectors
+template <typename T>
+__global__ void __launch_bounds__(BLOCK)
+ewald_zrot_kernel(const T* __restrict__ z, int n, double dk, double2* __restrict__ zrot) {
+  const int j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= n) return;
+  double ds, dc;
+  sincos(dk * (double)z[j], &ds, &dc);
+  zrot[j] = double2{dc, ds};
+}
 
 template <typename T>
 __global__ void __launch_bounds__(BLOCK)
 ewald_sk_rows_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, const T* __restrict__ m, int n,
-                     const double* __restrict__ kvec, const int2* __restrict__ rows, double dk, double* __restrict__ sk) {
+                     const double* __restrict__ kvec, const int2* __restrict__ rows, double dk, const double2* __restrict__ zrot,
+                     double* __restrict__ sk) {
   const int2 row = rows[blockIdx.x];
   __shared__ double red[BLOCK / 64][2 * ROWC];
   for (int c0 = 0; c0 < row.y; c0 += ROWC) {
@@ -199,9 +211,10 @@ ewald_sk_rows_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* 
     for (int e = 0; e < ROWC; ++e) { sc[e] = 0.0; ss[e] = 0.0; }
     for (int j = threadIdx.x; j < n; j += BLOCK) {
       const double pz = (double)z[j], mj = (double)m[j];
-      double s, c, ds, dc;
+      double s, c;
       sincos(kx * (double)x[j] + ky * (double)y[j] + kz * pz, &s, &c);
-      sincos(dk * pz, &ds, &dc);
+      const double2 rot = zrot[j];                       // (cos, sin)(dk z_j): the same for every row, computed once per evaluation
+      const double dc = rot.x, ds = rot.y;
 #pragma unroll
       for (int e = 0; e < ROWC; ++e) {
         sc[e] = fma(mj, c, sc[e]); ss[e] = fma(mj, s, ss[e]);
@@ -286,6 +299,8 @@ struct nb_ewald_state {
   int nrows = 0;
   float* table = nullptr;   // T(r^2) of the fp32 real-space kernel
   double table_L = 0, table_alphaL = 0;
+  double2* zrot = nullptr;  // [n] (cos, sin)(dk z_j)
+  int64_t zrot_cap = 0;
 };
 
 void nb_ewald_release(nb_ctx* c) {
@@ -294,6 +309,7 @@ void nb_ewald_release(nb_ctx* c) {
     if (c->ewald->sk) (void)hipFree(c->ewald->sk);
     if (c->ewald->table) (void)hipFree(c->ewald->table);
     if (c->ewald->rows) (void)hipFree(c->ewald->rows);
+    if (c->ewald->zrot) (void)hipFree(c->ewald->zrot);
     delete c->ewald; c->ewald = nullptr;
   }
 }
@@ -316,7 +332,15 @@ static int launch_recip(nb_ctx* c, nb_ewald_state& e, const T* x, const T* y, co
   const int nb = (int)((n + BLOCK - 1) / BLOCK);
   const double dk = 2.0 * 3.14159265358979323846 / L;
   if (by_rows) {
-    ewald_sk_rows_kernel<T><<<e.nrows, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, e.kvec, e.rows, dk, e.sk);
+    if (e.zrot_cap < n) {
+      NB_HIP(c, hipStreamSynchronize(c->stream));
+      if (e.zrot) { (void)hipFree(e.zrot); e.zrot = nullptr; e.zrot_cap = 0; }
+      NB_HIP(c, hipMalloc((void**)&e.zrot, (size_t)n * sizeof(double2)));
+      e.zrot_cap = n;
+    }
+    ewald_zrot_kernel<T><<<nb, BLOCK, 0, c->stream>>>(z, (int)n, dk, e.zrot);
+    NB_HIP(c, hipGetLastError());
+    ewald_sk_rows_kernel<T><<<e.nrows, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, e.kvec, e.rows, dk, e.zrot, e.sk);
     NB_HIP(c, hipGetLastError());
     ewald_recip_rows_kernel<T><<<nb, BLOCK, 0, c->stream>>>(x, y, z, (int)n, e.kvec, e.sk, e.rows, e.nrows, dk, G, ax, ay, az);
   } else {
