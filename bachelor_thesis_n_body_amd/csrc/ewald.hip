@@ -185,6 +185,20 @@ ewald_recip_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __
 // and ONE sincos of dk z per particle by complex rotation (4 fma per k-vector instead of an fp64 sincos).
 constexpr int ROWC = 36;        // k-vectors per pass of a row: a full row of kmax = 17 (fp32 contexts' default split) has 35 — one pass
 
+// sin and cos of a phase k.x computed in fp64. fp64 contexts: sincos(). fp32 contexts (forces good to ~1e-5 by contract): the phase is
+// reduced to (-1/2, 1/2] revolutions in fp64 and handed to the hardware's v_sin_f32 / v_cos_f32 (argument in revolutions, absolute error
+// ~5e-7) — a dozen instructions instead of the ~150 of the fp64 sincos, which was half of the work of a (row, particle) pair.
+template <typename T>
+__device__ inline void phase_sincos(double phase, double* s, double* c) {
+  if constexpr (sizeof(T) == 8) {
+    sincos(phase, s, c);
+  } else {
+    const double u = phase * 0.15915494309189535;          // revolutions
+    const float r = (float)(u - rint(u));
+    *s = (double)__builtin_amdgcn_sinf(r); *c = (double)__builtin_amdgcn_cosf(r);
+  }
+}
+
 // (cos, sin)(dk z_j): the step of the complex rotation along a row of k-vectors
 template <typename T>
 __global__ void __launch_bounds__(BLOCK)
@@ -212,7 +226,7 @@ ewald_sk_rows_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* 
     for (int j = threadIdx.x; j < n; j += BLOCK) {
       const double pz = (double)z[j], mj = (double)m[j];
       double s, c;
-      sincos(kx * (double)x[j] + ky * (double)y[j] + kz * pz, &s, &c);
+      phase_sincos<T>(kx * (double)x[j] + ky * (double)y[j] + kz * pz, &s, &c);
       const double2 rot = zrot[j];                       // (cos, sin)(dk z_j): the same for every row, computed once per evaluation
       const double dc = rot.x, ds = rot.y;
 #pragma unroll
@@ -263,7 +277,7 @@ ewald_recip_rows_kernel(const T* __restrict__ x, const T* __restrict__ y, const 
     __syncthreads();
     const double kx = kvec[4 * row.x], ky = kvec[4 * row.x + 1], kz0 = kvec[4 * row.x + 2];
     double s, c;
-    sincos(kx * px + ky * py + kz0 * pz, &s, &c);
+    phase_sincos<T>(kx * px + ky * py + kz0 * pz, &s, &c);
     double t0 = 0.0, tz = 0.0, kz = kz0;
     for (int e = 0; e < row.y; ++e) {
       const double t = -w[e] * (sc[e] * s - ss[e] * c);
