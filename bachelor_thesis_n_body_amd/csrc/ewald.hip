@@ -19,6 +19,7 @@
 #include "../../include/nbody_amd.h"
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -220,26 +221,32 @@ ewald_sk_rows_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* 
   for (int c0 = 0; c0 < row.y; c0 += ROWC) {
     const int q0 = row.x + c0, cnt = min(ROWC, row.y - c0);
     const double kx = kvec[4 * q0], ky = kvec[4 * q0 + 1], kz = kvec[4 * q0 + 2];
-    double sc[ROWC], ss[ROWC];
+    // fp64 contexts rotate and sum in fp64. fp32 contexts (forces good to ~1e-5 by contract) rotate and sum each thread's n / BLOCK
+    // particles in fp32 — 35 rotations lose ~2e-6, a thread's sum of ~1000 terms of either sign ~2e-6 of its size — and only the
+    // reduction over threads below is fp64: the inner loop runs at the fp32 rate, twice that of fp64
+    typedef typename std::conditional<sizeof(T) == 8, double, float>::type R;
+    R sc[ROWC], ss[ROWC];
 #pragma unroll
-    for (int e = 0; e < ROWC; ++e) { sc[e] = 0.0; ss[e] = 0.0; }
+    for (int e = 0; e < ROWC; ++e) { sc[e] = 0; ss[e] = 0; }
     for (int j = threadIdx.x; j < n; j += BLOCK) {
-      const double pz = (double)z[j], mj = (double)m[j];
-      double s, c;
-      phase_sincos<T>(kx * (double)x[j] + ky * (double)y[j] + kz * pz, &s, &c);
+      const double pz = (double)z[j];
+      const R mj = (R)m[j];
+      double s0, c0d;
+      phase_sincos<T>(kx * (double)x[j] + ky * (double)y[j] + kz * pz, &s0, &c0d);
       const double2 rot = zrot[j];                       // (cos, sin)(dk z_j): the same for every row, computed once per evaluation
-      const double dc = rot.x, ds = rot.y;
+      const R dc = (R)rot.x, ds = (R)rot.y;
+      R s = (R)s0, c = (R)c0d;
 #pragma unroll
       for (int e = 0; e < ROWC; ++e) {
         sc[e] = fma(mj, c, sc[e]); ss[e] = fma(mj, s, ss[e]);
-        const double cn = c * dc - s * ds;
+        const R cn = c * dc - s * ds;
         s = fma(s, dc, c * ds); c = cn;
       }
     }
     // fixed-order reduction: lanes of a wave by shuffles, then the waves through LDS
 #pragma unroll
     for (int e = 0; e < ROWC; ++e) {
-      double a = sc[e], b = ss[e];
+      double a = (double)sc[e], b = (double)ss[e];
       for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
       if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][2 * e] = a; red[threadIdx.x >> 6][2 * e + 1] = b; }
     }
@@ -259,34 +266,36 @@ ewald_recip_rows_kernel(const T* __restrict__ x, const T* __restrict__ y, const 
                         const double* __restrict__ kvec, const double* __restrict__ sk, const int2* __restrict__ rows, int nrows,
                         double dk, double G, T* __restrict__ ax, T* __restrict__ ay, T* __restrict__ az) {
   constexpr int MAXROW = 64;                               // >= 2 kmax + 1 for kmax <= 31
-  __shared__ double w[MAXROW], sc[MAXROW], ss[MAXROW];
+  typedef typename std::conditional<sizeof(T) == 8, double, float>::type R;   // a row's terms in fp32 for fp32 contexts (as in ewald_sk_rows_kernel);
+  __shared__ R w[MAXROW], sc[MAXROW], ss[MAXROW];                               // the sum over rows stays fp64
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   const bool live = i < n;
   const int ic = live ? i : n - 1;
   const double px = (double)x[ic], py = (double)y[ic], pz = (double)z[ic];
-  double ds, dc;
-  sincos(dk * pz, &ds, &dc);
+  double dsd, dcd;
+  sincos(dk * pz, &dsd, &dcd);
+  const R ds = (R)dsd, dc = (R)dcd, dkr = (R)dk;
   double fx = 0.0, fy = 0.0, fz = 0.0;
   for (int r = 0; r < nrows; ++r) {
     const int2 row = rows[r];
     __syncthreads();
     if ((int)threadIdx.x < row.y) {
       const int q = row.x + threadIdx.x;
-      w[threadIdx.x] = kvec[4 * q + 3]; sc[threadIdx.x] = sk[2 * q]; ss[threadIdx.x] = sk[2 * q + 1];
+      w[threadIdx.x] = (R)kvec[4 * q + 3]; sc[threadIdx.x] = (R)sk[2 * q]; ss[threadIdx.x] = (R)sk[2 * q + 1];
     }
     __syncthreads();
     const double kx = kvec[4 * row.x], ky = kvec[4 * row.x + 1], kz0 = kvec[4 * row.x + 2];
-    double s, c;
-    phase_sincos<T>(kx * px + ky * py + kz0 * pz, &s, &c);
-    double t0 = 0.0, tz = 0.0, kz = kz0;
+    double s0, c0;
+    phase_sincos<T>(kx * px + ky * py + kz0 * pz, &s0, &c0);
+    R s = (R)s0, c = (R)c0, t0 = 0, tz = 0, kz = (R)kz0;
     for (int e = 0; e < row.y; ++e) {
-      const double t = -w[e] * (sc[e] * s - ss[e] * c);
+      const R t = -w[e] * (sc[e] * s - ss[e] * c);
       t0 += t; tz = fma(t, kz, tz);
-      const double cn = c * dc - s * ds;
+      const R cn = c * dc - s * ds;
       s = fma(s, dc, c * ds); c = cn;
-      kz += dk;
+      kz += dkr;
     }
-    fx = fma(t0, kx, fx); fy = fma(t0, ky, fy); fz += tz;
+    fx = fma((double)t0, kx, fx); fy = fma((double)t0, ky, fy); fz += (double)tz;
   }
   if (live) { ax[i] = (T)((double)ax[i] + G * fx); ay[i] = (T)((double)ay[i] + G * fy); az[i] = (T)((double)az[i] + G * fz); }
 }
