@@ -443,20 +443,27 @@ int nb_kdk_run(nb_ctx* c, int64_t nsteps, const double* kick1, const double* dri
       ok = !rcc && ec == hipSuccess && g != nullptr && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
     }
     (void)hipGetLastError();                          // a refused capture must not poison the eager fallback
+    // Two different failures: capture / instantiate refused (nothing was enqueued: the state is the one after step 0 and the eager loop
+    // takes over from step 1), or a replay failed part-way (steps 1..launched ran and advanced the device step counter: the eager loop
+    // continues from step 1 + launched once the stream has drained — never from step 1 again).
+    int64_t launched = 0;
+    bool replay_failed = false;
     if (ok) {
-      for (int64_t k = 1; k < nsteps && ok; ++k) ok = hipGraphLaunch(ge, c->stream) == hipSuccess;
-      if (ok) k0 = nsteps;
-    }
-    if (!ok && k0 == 1) {                             // nothing was replayed: the state is still the one after step 0
+      for (int64_t k = 1; k < nsteps; ++k) {
+        if (hipGraphLaunch(ge, c->stream) != hipSuccess) { replay_failed = true; break; }
+        ++launched;
+      }
+    } else {
       c->err.clear();
     }
     hipError_t es = hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
     if (ge) (void)hipGraphExecDestroy(ge);
     if (g) (void)hipGraphDestroy(g);
     (void)hipFree(dfac);
     if (es != hipSuccess) return nb_fail(c, NB_ERR_HIP, std::string("nb_kdk_run (graph replay): ") + hipGetErrorString(es));
-    if (!ok && k0 != 1) return nb_fail(c, NB_ERR_HIP, "nb_kdk_run: hipGraphLaunch failed part-way through the run");
-    c->graph_replayed = ok;
+    k0 = 1 + launched;                                // the replays that were enqueued have completed (synchronised above)
+    c->graph_replayed = ok && !replay_failed;
   }
   for (int64_t k = k0; k < nsteps; ++k) { rc = kdk_enqueue(c, kick1[k], drift[k], kick2[k], eps, G); if (rc) return rc; }
   NB_HIP(c, hipStreamSynchronize(c->stream));       // the only host round trip of the run
@@ -496,11 +503,12 @@ int nb_rung_step(nb_ctx* c, int levels, const double* kc, const double* dc, doub
                                 eps * eps, G, ax, ay, az);
   };
   c->acc_valid = false;                    // the state's acc arrays hold the short-range part only from here on
-  if (!c->lr_valid) {
+  if (!c->lr_valid || c->lr_eps != eps || c->lr_G != G) {   // the cached a_lr / a_sr belong to one (eps, G)
+    c->lr_valid = false;
     rc = force(1); if (rc) return rc;
     NB_HIP(c, hipMemcpyAsync(c->acc_lr, ax, 3 * b, hipMemcpyDeviceToDevice, c->stream));
     rc = force(2); if (rc) return rc;
-    c->lr_valid = true;
+    c->lr_valid = true; c->lr_eps = eps; c->lr_G = G;
   }
   // rungs from the short-range acceleration at the start of the base step
   NB_HIP(c, hipMemsetAsync(c->rung_hist, 0, 16 * sizeof(int), c->stream));

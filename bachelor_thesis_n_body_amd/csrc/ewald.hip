@@ -225,10 +225,18 @@ ewald_sk_rows_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* 
     // particles in fp32 — 35 rotations lose ~2e-6, a thread's sum of ~1000 terms of either sign ~2e-6 of its size — and only the
     // reduction over threads below is fp64: the inner loop runs at the fp32 rate, twice that of fp64
     typedef typename std::conditional<sizeof(T) == 8, double, float>::type R;
+    // fp32 contexts: a thread's fp32 sums live for SK_FLUSH of its particles only, then go through the fp64 reduction below — the
+    // rounding error of S(k), a small residual of large cancelling terms, must not grow with n / BLOCK (128^3 particles: 8 flushes)
+    constexpr int SK_FLUSH = 1024;
+    const int chunk = sizeof(T) == 8 ? n : SK_FLUSH * BLOCK;
+    if (threadIdx.x < 2 * ROWC) for (int w = 0; w < BLOCK / 64; ++w) red[w][threadIdx.x] = 0.0;
+    __syncthreads();
+    for (int jb = 0; jb < n; jb += chunk) {
+    const int je = min(n, jb + chunk);
     R sc[ROWC], ss[ROWC];
 #pragma unroll
     for (int e = 0; e < ROWC; ++e) { sc[e] = 0; ss[e] = 0; }
-    for (int j = threadIdx.x; j < n; j += BLOCK) {
+    for (int j = jb + threadIdx.x; j < je; j += BLOCK) {
       const double pz = (double)z[j];
       const R mj = (R)m[j];
       double s0, c0d;
@@ -248,7 +256,8 @@ ewald_sk_rows_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* 
     for (int e = 0; e < ROWC; ++e) {
       double a = (double)sc[e], b = (double)ss[e];
       for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
-      if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][2 * e] = a; red[threadIdx.x >> 6][2 * e + 1] = b; }
+      if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][2 * e] += a; red[threadIdx.x >> 6][2 * e + 1] += b; }   // own slot of this wave: fixed order
+    }
     }
     __syncthreads();
     if ((int)threadIdx.x < 2 * cnt) {

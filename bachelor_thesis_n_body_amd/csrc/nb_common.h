@@ -40,7 +40,8 @@ struct nb_ctx {
   size_t rung_tab_len = 0;
   const unsigned char* sr_rung = nullptr;   // when set: the pair kernel skips chunks without a particle on rung >= sr_min_rung (nb_rung_step)
   int sr_min_rung = 0;
-  bool lr_valid = false;             // acc_lr / the state's acc hold a_lr / a_sr of the current positions
+  bool lr_valid = false;             // acc_lr / the state's acc hold a_lr / a_sr of the current positions, computed with (lr_eps, lr_G)
+  double lr_eps = -1.0, lr_G = 0.0;
   bool graph_replayed = false;   // the last nb_kdk_run replayed a captured step (diagnostic: nb_last_run_used_graph)
   // force solver used by nb_accel / nb_step: direct summation (default) or Barnes-Hut tree (fp32 only)
   int solver = 0;

@@ -59,6 +59,17 @@ def measured_traffic():
         return None
 
 
+def _is_profiler_var(key, value):
+    """Environment a rocprofv3 / rocprofiler-sdk session injects into the program it profiles."""
+    if key.startswith(("ROCPROF", "ROCPROFILER_", "ROCP_", "ROCTX_")) or key in ("HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE"):
+        return True
+    return key == "LD_PRELOAD" and "rocprof" in value.lower()
+
+
+def under_profiler():
+    return any(_is_profiler_var(k, v) for k, v in os.environ.items())
+
+
 def live_traffic(args, timeout_s=150):
     """HBM bytes per accel launch of THIS workload, measured now: two child runs of this script (one step, no CPU baseline) under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only — the guide's prescription), FETCH_SIZE doubled
@@ -72,7 +83,11 @@ def live_traffic(args, timeout_s=150):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None, "rocprofv3 not found"
+    if under_profiler():
+        return None, "already under a profiler (nested counter sessions are not started)"
     vals = {}
+    child_env = {k: v for k, v in os.environ.items() if not _is_profiler_var(k, v)}
+    child_env["TMPDIR"] = "/tmp"
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="nb_pmc_", dir="/tmp")
         cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, str(Path(__file__).resolve()),
@@ -81,7 +96,7 @@ def live_traffic(args, timeout_s=150):
         if args.general_mass:
             cmd.append("--general-mass")
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            r = subprocess.run(cmd, cwd="/tmp", env=child_env, capture_output=True, text=True, timeout=timeout_s)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} exited with {r.returncode}"
             per = []

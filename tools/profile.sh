@@ -7,7 +7,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 OUT=${PROF_OUT:-gpurun_out/prof}; rm -rf $OUT; mkdir -p $OUT
 FP=F32; case "$*" in *f64*) FP=F64;; esac
-B="python3 bench.py --no-cpu-baseline --no-clock-probe $*"
+B="python3 bench.py --no-cpu-baseline --no-clock-probe --traffic none $*"   # --traffic none: bench.py must not start its own rocprofv3 children under this profiler
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 3 --warmup 1 > $OUT/trace.out 2>&1 || exit 1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcA -- $B --steps 1 --warmup 0 > $OUT/pmcA.out 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_VALU_TRANS_$FP SQ_INSTS_VALU_FMA_$FP SQ_INSTS_VALU_MUL_$FP SQ_INSTS_VALU_ADD_$FP SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmcB -- $B --steps 1 --warmup 0 > $OUT/pmcB.out 2>&1 || exit 1
