@@ -1,0 +1,368 @@
+// fp32 softened all-pairs acceleration of a particle set ON ITSELF, each unordered pair evaluated ONCE (Newton's third law) —
+// SURVEY.md §8(a) row ⊕1 for the self-interaction case (sinks == sources: nb_accel / nb_step, the own-chunk launch of a sharded run).
+//
+//   a_i = G * sum_j m_j (r_j - r_i) / (|r_j - r_i|^2 + eps^2)^{3/2}
+//
+// accel_f32.hip sits at its instruction-issue floor (11 full-rate VALU + 1 v_rsq_f32 per ORDERED pair). The pair term
+// s_ij (r_j - r_i) serves both particles: evaluated once, the r^2 / rsqrt / cube work (8 + 1 of those 12 instructions) is shared and
+// only the second accumulation (3 fma) is added — 14 full-rate + 1 transcendental per UNORDERED pair = 7 + 1/2 per ordered pair.
+// What that needs is a place for the second particle's sum. On a GPU the classic sink-per-lane loop reads every source as a wave-wide
+// BROADCAST, so all 64 lanes would owe a contribution to the same source at the same time (a 64-lane reduction per source: dearer than
+// the work saved). Here the walk is SKEWED instead:
+//
+//  * particles are cut into SETS of 256*KS; block (b, y) keeps set b in VGPRs as sinks (KS per lane, packed pairs, as accel_f32) and
+//    walks the sets c = b + d (mod nsets) for the offsets d of its group y; d = 1 .. (nsets-1)/2 covers every unordered pair of
+//    distinct sets exactly once. d = 0 (a set with itself) and, for an even set count, d = nsets/2 (met from both sides) are walked
+//    one-sidedly (no second accumulation): 2 of nsets/2 + 1 tiles.
+//  * a set streams through LDS in tiles of TJ sources. In step t lane l of a wave meets source (t + l) mod TJ — every lane a DIFFERENT
+//    source, read with one conflict-free ds_read_b128 per lane (the tile carries 64 wrap-around copies, so the address is base + t).
+//    The lane adds the pair's term to its sinks in registers and the opposite term to the source's accumulator in LDS — a plain
+//    read / add / write of 64 different addresses per instruction: no conflicts, no reduction, no atomics (measured: the same walk
+//    with ds_add_f32 runs 6x slower — LDS float atomics retire a few lanes per clock). Each wave owns a private copy of the tile's
+//    accumulators; the entry lane l updates in step t is the one lane l + 1 updated in step t - 1, and within a wave LDS operations
+//    complete in program order, so the sums are exact and bit-reproducible.
+//  * after a tile the block adds its waves' copies in a fixed order and stores the tile's partial accelerations to a slab
+//    [offset][3][n] (fp32, written once, no atomics); the sinks' own sums go to an fp64 slab [group][3][n]; a second kernel adds
+//    both in a fixed order. Slab traffic at N = 2^20: 3.2 GB written + read per launch (~1 ms of ~150).
+//  * accuracy as accel_f32: fp32 partial sums live for one tile (sinks) / one set of 256*KS sinks (sources) and are then widened.
+#include "nb_common.h"
+#include "../../include/nbody_amd.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// one staged source; equal masses: the 12 bytes of the position only (ds_read_b96 — a b128 read would also write the register of the
+// unused mass, which the compiler re-uses, and stall on that write)
+struct alignas(16) f3 { float x, y, z; };
+template <bool UNIFORM> __device__ inline float4 ld_src(const float4* p) {
+  if (UNIFORM) { const f3 v = *reinterpret_cast<const f3*>(p); return make_float4(v.x, v.y, v.z, 0.f); }
+  return *p;
+}
+
+// Offsets of this launch are numbered o = 0 .. : o = 0 -> d = 0 (one-sided), o = 1 .. H -> d = o (two-sided), o = H + 1 -> d = nsets / 2
+// (one-sided; only when nsets is even). Block (b, y) walks o in [o_begin + y * o_per_group, ...) capped at o_end.
+template <int KS, int U, int TJ, bool GUARD, bool UNIFORM>
+__global__ void __launch_bounds__(BLOCK)
+accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ m,
+                     int n, int nsets, int H, int o_begin, int o_end, int o_per_group, int slot0, float eps2,
+                     double* __restrict__ part, float* __restrict__ slab, size_t n_pad) {
+  static_assert(KS % 2 == 0 && TJ % BLOCK == 0 && TJ % U == 0, "shape");
+  constexpr int SET = BLOCK * KS;
+  constexpr int KP = KS / 2;
+  constexpr int AS = TJ + 64;        // tile entries incl. the 64 wrap-around copies
+  constexpr int LPT = TJ / BLOCK;
+  constexpr int QT = SET / TJ;       // tiles per set
+  __shared__ float4 tile[AS];
+  constexpr int AW = 2;              // the two halves of a packed partial sum keep separate accumulators (no add per step)
+  __shared__ float acc[WAVES][3][AS * AW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.x;
+  const int i0 = b * SET + tid;
+  const float far = 1e20f;           // UNIFORM padding: r^2 overflows to +inf, v_rsq_f32(+inf) = +0, every term exactly 0
+
+  v2f px[KP], py[KP], pz[KP], pm[KP];
+#pragma unroll
+  for (int p = 0; p < KP; ++p) {
+    const int ia = i0 + (2 * p) * BLOCK, ib = ia + BLOCK;
+    const bool oa = ia < n, ob = ib < n;
+    const int ca = oa ? ia : n - 1, cb = ob ? ib : n - 1;
+    if (UNIFORM) {
+      px[p] = v2f{oa ? x[ca] : far, ob ? x[cb] : far}; py[p] = v2f{oa ? y[ca] : far, ob ? y[cb] : far}; pz[p] = v2f{oa ? z[ca] : far, ob ? z[cb] : far};
+      pm[p] = v2f{0.f, 0.f};
+    } else {                         // padded sinks: a real position with zero mass (they push nothing onto the sources)
+      px[p] = v2f{x[ca], x[cb]}; py[p] = v2f{y[ca], y[cb]}; pz[p] = v2f{z[ca], z[cb]};
+      pm[p] = v2f{oa ? m[ca] : 0.f, ob ? m[cb] : 0.f};
+    }
+  }
+  double tx[KS], ty[KS], tz[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) { tx[k] = 0.0; ty[k] = 0.0; tz[k] = 0.0; }
+  v2f e2;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2" : "=v"(e2.x), "=v"(e2.y) : "s"(eps2));
+
+  for (int e = tid; e < WAVES * 3 * AS * AW; e += BLOCK) (&acc[0][0][0])[e] = 0.f;
+
+  const int o_lo = o_begin + blockIdx.y * o_per_group;
+  const int o_hi = min(o_end, o_lo + o_per_group);
+  const int ntiles = max(0, o_hi - o_lo) * QT;
+
+  auto set_of = [&](int o) { const int d = o <= H ? o : nsets / 2; int c = b + d; return c >= nsets ? c - nsets : c; };
+
+  float4 stage[LPT];
+  auto fetch = [&](int T) {
+    const int c = set_of(o_lo + T / QT), q = T % QT;
+#pragma unroll
+    for (int l = 0; l < LPT; ++l) {
+      const int j = c * SET + q * TJ + l * BLOCK + tid;
+      const bool ok = j < n;
+      const int jc = ok ? j : n - 1;
+      stage[l] = UNIFORM ? make_float4(ok ? x[jc] : far, ok ? y[jc] : far, ok ? z[jc] : far, 0.0f)
+                         : make_float4(x[jc], y[jc], z[jc], ok ? m[jc] : 0.0f);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int l = 0; l < LPT; ++l) tile[l * BLOCK + tid] = stage[l];
+    if (tid < 64) tile[TJ + tid] = stage[0];       // wrap-around copies of entries 0..63
+  };
+
+  if (ntiles > 0) { fetch(0); commit(); }
+#pragma unroll
+  for (int p = 0; p < KP; ++p) asm volatile("" : "+v"(px[p]), "+v"(py[p]), "+v"(pz[p]), "+v"(pm[p]));
+  __syncthreads();
+
+  const float4* tl = tile + lane;
+  float* ac = &acc[wv][0][lane * AW];
+
+  auto walk = [&](auto symtag) {
+    constexpr bool SYM = decltype(symtag)::value;
+    v2f fx[KP], fy[KP], fz[KP];
+#pragma unroll
+    for (int p = 0; p < KP; ++p) { fx[p] = v2f{0.f, 0.f}; fy[p] = v2f{0.f, 0.f}; fz[p] = v2f{0.f, 0.f}; }
+    // step t: lane l meets the sources t + u * TJ/U + l (u < U) — 64 different sources per instruction, and the U sets of a step are disjoint.
+    // The sources of step t + 1 are read during step t into the other of two register sets (the tile has 64 entries beyond the last
+    // step's); the accumulators of a step are read at its top and consumed at its end (the scheduler may not pull the source-side
+    // chains above the sink-side work), so no LDS round trip is exposed.
+    constexpr int HS = TJ / U;
+    auto step = [&](float4 (&s)[U], float4 (&nx)[U], int t) {
+      v2f gx[U], gy[U], gz[U];
+      // lane l reads the accumulator lane l + 1 wrote one step earlier (same wave: LDS operations complete in program order); the
+      // compiler sees only this lane's addresses, so no LDS access may be moved across a step boundary
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        nx[u] = ld_src<UNIFORM>(tl + t + 1 + u * HS);
+      }
+      if (SYM) {   // the source's running sums start the partial-sum chains of this step
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          gx[u] = *reinterpret_cast<const v2f*>(ac + (0 * AS + t + u * HS) * 2);
+          gy[u] = *reinterpret_cast<const v2f*>(ac + (1 * AS + t + u * HS) * 2);
+          gz[u] = *reinterpret_cast<const v2f*>(ac + (2 * AS + t + u * HS) * 2);
+        }
+      }
+      v2f dx[U][KP], dy[U][KP], dz[U][KP], r2[U][KP], rinv[U][KP], r3[U][KP];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+          dx[u][p] = v2f{s[u].x, s[u].x} - px[p];
+          dy[u][p] = v2f{s[u].y, s[u].y} - py[p];
+          dz[u][p] = v2f{s[u].z, s[u].z} - pz[p];
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int p = 0; p < KP; ++p)
+          r2[u][p] = __builtin_elementwise_fma(dx[u][p], dx[u][p], __builtin_elementwise_fma(dy[u][p], dy[u][p], __builtin_elementwise_fma(dz[u][p], dz[u][p], e2)));
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+          rinv[u][p] = v2f{__builtin_amdgcn_rsqf(r2[u][p].x), __builtin_amdgcn_rsqf(r2[u][p].y)};
+          if (GUARD) {
+            rinv[u][p].x = r2[u][p].x > e2.x ? rinv[u][p].x : 0.0f;
+            rinv[u][p].y = r2[u][p].y > e2.y ? rinv[u][p].y : 0.0f;
+          }
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+          r3[u][p] = (rinv[u][p] * rinv[u][p]) * rinv[u][p];
+          const v2f fi = UNIFORM ? r3[u][p] : r3[u][p] * v2f{s[u].w, s[u].w};      // factor of the sinks' sums: m_j / r^3
+          fx[p] = __builtin_elementwise_fma(fi, dx[u][p], fx[p]);
+          fy[p] = __builtin_elementwise_fma(fi, dy[u][p], fy[p]);
+          fz[p] = __builtin_elementwise_fma(fi, dz[u][p], fz[p]);
+        }
+      if (SYM) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int p = 0; p < KP; ++p) {                                   // a_j -= fj (r_j - r_i)
+            const v2f fj = UNIFORM ? r3[u][p] : r3[u][p] * pm[p];        // factor of the source's sum: m_i / r^3
+            gx[u] = __builtin_elementwise_fma(-fj, dx[u][p], gx[u]);
+            gy[u] = __builtin_elementwise_fma(-fj, dy[u][p], gy[u]);
+            gz[u] = __builtin_elementwise_fma(-fj, dz[u][p], gz[u]);
+          }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          *reinterpret_cast<v2f*>(ac + (0 * AS + t + u * HS) * 2) = gx[u];
+          *reinterpret_cast<v2f*>(ac + (1 * AS + t + u * HS) * 2) = gy[u];
+          *reinterpret_cast<v2f*>(ac + (2 * AS + t + u * HS) * 2) = gz[u];
+        }
+      }
+    };
+    float4 sa[U], sb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) sa[u] = ld_src<UNIFORM>(tl + u * HS);
+    static_assert(HS % 2 == 0, "steps are taken in pairs");
+    for (int t = 0; t < HS; t += 2) { step(sa, sb, t); step(sb, sa, t + 1); }
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+      tx[2 * p] += (double)fx[p].x; ty[2 * p] += (double)fy[p].x; tz[2 * p] += (double)fz[p].x;
+      tx[2 * p + 1] += (double)fx[p].y; ty[2 * p + 1] += (double)fy[p].y; tz[2 * p + 1] += (double)fz[p].y;
+    }
+  };
+
+  for (int T = 0; T < ntiles; ++T) {
+    const int o = o_lo + T / QT, q = T % QT;
+    const bool sym = o >= 1 && o <= H;
+    if (T + 1 < ntiles) fetch(T + 1);
+    if (sym) walk(std::true_type{}); else walk(std::false_type{});
+    __syncthreads();                                   // every wave has finished the tile: accumulators complete, tile free
+    if (sym) {
+      const int c = set_of(o);
+      float* sl = slab + (size_t)(slot0 + o - max(o_begin, 1)) * 3 * n_pad + (size_t)c * SET + (size_t)q * TJ;
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+        for (int e = tid; e < TJ; e += BLOCK) {
+          float v = 0.f;
+#pragma unroll
+          for (int w2 = 0; w2 < WAVES; ++w2)
+#pragma unroll
+            for (int h = 0; h < AW; ++h) { v += acc[w2][cc][e * AW + h]; acc[w2][cc][e * AW + h] = 0.f; }
+          if (e < 64) {
+#pragma unroll
+            for (int w2 = 0; w2 < WAVES; ++w2)
+#pragma unroll
+              for (int h = 0; h < AW; ++h) { v += acc[w2][cc][(TJ + e) * AW + h]; acc[w2][cc][(TJ + e) * AW + h] = 0.f; }
+          }
+          sl[(size_t)cc * n_pad + e] = v;
+        }
+    }
+    if (T + 1 < ntiles) commit();
+    __syncthreads();
+  }
+
+  double* pp = part + (size_t)blockIdx.y * 3 * n_pad;
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int i = i0 + k * BLOCK;
+    if (i < n) { pp[i] = tx[k]; pp[n_pad + i] = ty[k]; pp[2 * n_pad + i] = tz[k]; }
+  }
+}
+
+// a[c][i] (+)= g * ( sum_y part[y][c][i] + sum_s slab[s][c][i] ), fixed order; `tot` non-null: the sums of several passes are collected in
+// fp64 first (first: tot = sum, otherwise tot += sum) and turned into accelerations by the last pass
+__global__ void __launch_bounds__(256)
+accel_sym_reduce_f32_kernel(const double* __restrict__ part, int ngroups, const float* __restrict__ slab, int nslots, int n, size_t n_pad,
+                            float G, const float* __restrict__ m0, double* __restrict__ tot, int first, int last,
+                            float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  for (int g = 0; g < ngroups; ++g) {
+    const double* p = part + (size_t)g * 3 * n_pad;
+    sx += p[i]; sy += p[n_pad + i]; sz += p[2 * n_pad + i];
+  }
+#pragma unroll 8
+  for (int s = 0; s < nslots; ++s) {
+    const float* p = slab + (size_t)s * 3 * n_pad;
+    sx += (double)p[i]; sy += (double)p[n_pad + i]; sz += (double)p[2 * n_pad + i];
+  }
+  if (tot) {
+    if (!first) { sx += tot[i]; sy += tot[(size_t)n + i]; sz += tot[2 * (size_t)n + i]; }
+    if (!last) { tot[i] = sx; tot[(size_t)n + i] = sy; tot[2 * (size_t)n + i] = sz; return; }
+  }
+  const double g = m0 ? (double)G * (double)m0[0] : (double)G;
+  float ox = (float)(g * sx), oy = (float)(g * sy), oz = (float)(g * sz);
+  if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
+  ax[i] = ox; ay[i] = oy; az[i] = oz;
+}
+
+long long env_ll(const char* name, long long dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoll(v) : dflt;
+}
+
+template <int KS, int U>
+int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
+            float eps2, float G, float* ax, float* ay, float* az, int flags, long long budget, long long env_groups) {
+  constexpr int TJ = 512, SET = BLOCK * KS;
+  const int nsets = (int)((n + SET - 1) / SET);
+  const size_t n_pad = (size_t)nsets * SET;
+  const int H = (nsets - 1) / 2;
+  const int n_o = H + 1 + (nsets % 2 == 0 ? 1 : 0);          // offsets incl. the one-sided ones
+  const size_t slot_bytes = 3 * n_pad * sizeof(float);
+  int slots_per_pass = (int)std::max<long long>(1, budget / (long long)slot_bytes);
+  if (slots_per_pass > H) slots_per_pass = H > 0 ? H : 1;
+  // pass 0 takes o = 0 and the first two-sided offsets, the last pass also the one-sided half offset
+  const int npass = H > 0 ? (H + slots_per_pass - 1) / slots_per_pass : 1;
+  // groups: ~4096 blocks over the launch (see accel_f32.hip's split sweep)
+  int groups_total = env_groups > 0 ? (int)env_groups : (4096 + nsets - 1) / nsets;
+  if (groups_total < 1) groups_total = 1;
+  if (groups_total > n_o) groups_total = n_o;
+  const int opg = (n_o + groups_total - 1) / groups_total;   // offsets per group
+  const int max_groups_pass = (slots_per_pass + 2 + opg - 1) / opg + 1;
+  const size_t part_bytes = (size_t)max_groups_pass * 3 * n_pad * sizeof(double);
+  const size_t slab_bytes = (size_t)slots_per_pass * slot_bytes;
+  const size_t tot_bytes = npass > 1 ? 3 * (size_t)n * sizeof(double) : 0;
+  int rc = nb_ensure_work(c, part_bytes + slab_bytes + tot_bytes);
+  if (rc) return rc;
+  double* part = reinterpret_cast<double*>(c->work);
+  float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(c->work) + part_bytes);
+  double* tot = npass > 1 ? reinterpret_cast<double*>(reinterpret_cast<char*>(c->work) + part_bytes + slab_bytes) : nullptr;
+  const bool uniform = (flags & NB_UNIFORM_MASS) != 0;
+  const bool guard = !(eps2 >= 1e-20f);
+  const int accumulate = flags & NB_ACCUMULATE;
+  for (int ps = 0; ps < npass; ++ps) {
+    // two-sided offsets of this pass: o in [1 + ps * spp, 1 + min(H, (ps + 1) * spp)); o = 0 rides with pass 0, o = H + 1 with the last
+    const int s_begin = 1 + ps * slots_per_pass, s_end = 1 + std::min(H, (ps + 1) * slots_per_pass);
+    const int o_begin = ps == 0 ? 0 : s_begin;
+    const int o_end = (ps == npass - 1) ? n_o : s_end;
+    const int ngroups = (o_end - o_begin + opg - 1) / opg;
+    const int nslots = std::max(0, s_end - s_begin);
+    if (ngroups > max_groups_pass) return nb_fail(c, NB_ERR_ARG, "accel_sym_f32: internal group count");
+    dim3 grid(nsets, ngroups);
+#define NB_SYM_GO(GD, UF) accel_sym_f32_kernel<KS, U, TJ, GD, UF><<<grid, BLOCK, 0, c->stream>>>( \
+    x, y, z, m, (int)n, nsets, H, o_begin, o_end, opg, 0, eps2, part, slab, n_pad)
+    if constexpr (KS == 12) {            // equal masses only
+      if (guard) NB_SYM_GO(true, true); else NB_SYM_GO(false, true);
+    } else {
+      if (guard) { if (uniform) NB_SYM_GO(true, true); else NB_SYM_GO(true, false); }
+      else       { if (uniform) NB_SYM_GO(false, true); else NB_SYM_GO(false, false); }
+    }
+#undef NB_SYM_GO
+    NB_HIP(c, hipGetLastError());
+    accel_sym_reduce_f32_kernel<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(part, ngroups, slab, nslots, (int)n, n_pad, G,
+                                                                                 uniform ? m : nullptr, tot, ps == 0, ps == npass - 1,
+                                                                                 ax, ay, az, accumulate);
+    NB_HIP(c, hipGetLastError());
+  }
+  return NB_OK;
+}
+
+}  // namespace
+
+// Self-interaction launch (sinks == sources). Returns NB_OK and sets *taken = 1 when the pair-symmetric kernel ran, *taken = 0 when the
+// caller should use the one-sided kernel (small n, fused potential, switched off with NB_F32_SYM=0).
+int nb_launch_accel_sym_f32(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
+                            float eps2, float G, float* ax, float* ay, float* az, int flags, int* taken) {
+  *taken = 0;
+  static const long long mode = env_ll("NB_F32_SYM", 1), min_n = env_ll("NB_F32_SYM_MIN_N", 32768),
+                         budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_groups = env_ll("NB_F32_SYM_GROUPS", 0);
+  if (!mode || n < min_n || n >= (1ll << 31) || n <= BLOCK * 4) return NB_OK;
+  // Sinks per lane (set = 256 * KS particles). Equal masses, large n: 12 sinks x 1 source per step (244 VGPRs; fewest accumulator round trips
+  // per pair: 159.6 ms at N = 2^20 against 163.7 with 8 sinks x 2 sources, one box); per-particle masses carry two more registers per sink
+  // pair: 8 x 2. Smaller n: smaller sets, so that the launch still has a few thousand (set, offset) tiles to spread over 256 CUs.
+  auto tiles = [&](int ks) { const long long ns = (n + BLOCK * ks - 1) / (BLOCK * ks); return ns * ((ns - 1) / 2 + 1); };
+  static const long long env_ks = env_ll("NB_F32_SYM_KS", 0);
+  int ks = (flags & NB_UNIFORM_MASS) ? 12 : 8;
+  if (ks == 12 && tiles(12) < 2500) ks = 8;
+  if (ks == 8 && tiles(8) < 2500) ks = 4;
+  if (env_ks == 4 || env_ks == 8 || (env_ks == 12 && (flags & NB_UNIFORM_MASS))) ks = (int)env_ks;
+  const int rc = ks == 12 ? run_sym<12, 1>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups)
+               : ks == 8  ? run_sym<8, 2>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups)
+                          : run_sym<4, 2>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups);
+  if (rc) return rc;
+  *taken = 1;
+  return NB_OK;
+}

@@ -1,0 +1,272 @@
+// fp64 softened all-pairs acceleration of a particle set ON ITSELF, each unordered pair evaluated once — the fp64 twin of
+// accel_sym_f32.hip (same skewed walk, same slabs; SURVEY.md §8(a) row ⊕1, configs[3]).
+//
+// accel_f64.hip spends 13 fp64 VALU + the v_rsq_f64 seed per ORDERED pair. Here a pair costs 3 sub, 3 fma (r^2), the seed, 4 for
+// (2/3) r^-3 (accel_f64.hip's first-order refinement: u = y*y; q = fma(-r2, u, 5/3); f = (u*y)*q), 3 fma for the sink and 3 fma for the
+// source: 16 + seed per UNORDERED pair = 8 + 1/2 per ordered pair (per-particle masses: two more multiplies per unordered pair).
+//  * sets of 256*KS particles; block (b, y) holds set b as sinks (KS per lane) and walks the sets b + d for the offsets d of its group
+//    (d = 1 .. (nsets-1)/2 two-sided; d = 0 and, for an even set count, d = nsets/2 one-sided);
+//  * in step t lane l meets source (t + l) mod TJ of the staged tile — 64 different sources per instruction (per-lane ds_read, the tile
+//    carries 64 wrap-around copies) — adds the pair term to its sinks in registers and the opposite term to the source's running sum in
+//    LDS by a plain read / add / write: 64 different addresses per instruction, a private accumulator copy per wave, and the entry lane l
+//    updates in step t is the one lane l + 1 updated in step t - 1 (LDS operations of a wave complete in order): exact, bit-reproducible;
+//  * per tile the waves' copies are added in a fixed order and stored to an fp64 slab [offset][3][n]; the sinks' sums go to a slab
+//    [group][3][n]; a second kernel adds everything in a fixed order. No atomics anywhere.
+#include "nb_common.h"
+#include "../../include/nbody_amd.h"
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+constexpr double F_SCALE = 1.5;     // the 3/2 of the first-order rsqrt refinement, applied with G in the epilogue (see accel_f64.hip)
+struct alignas(16) d4 { double x, y, z, w; };
+struct alignas(16) d3 { double x, y, z; };
+
+template <bool UNIFORM> __device__ inline d4 ld_src(const d4* p) {
+  if (UNIFORM) { const d3 v = *reinterpret_cast<const d3*>(p); return d4{v.x, v.y, v.z, 0.0}; }
+  return *p;
+}
+
+template <int KS, int TJ, bool GUARD, bool UNIFORM>
+__global__ void __launch_bounds__(BLOCK)
+accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z, const double* __restrict__ m,
+                     int n, int nsets, int H, int o_begin, int o_end, int o_per_group, double eps2,
+                     double* __restrict__ part, double* __restrict__ slab, size_t n_pad) {
+  static_assert(TJ % BLOCK == 0 && TJ % 2 == 0, "shape");
+  constexpr int SET = BLOCK * KS;
+  constexpr int AS = TJ + 64;
+  constexpr int LPT = TJ / BLOCK;
+  constexpr int QT = SET / TJ;
+  static_assert(SET % TJ == 0, "a set is a whole number of tiles");
+  __shared__ d4 tile[AS];
+  __shared__ double acc[WAVES][3][AS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.x;
+  const int i0 = b * SET + tid;
+  const double far = 1e150;          // UNIFORM padding: y = r2^-1/2 ~ 1e-150, y^3 underflows to exactly 0
+
+  double px[KS], py[KS], pz[KS], pm[KS], fx[KS], fy[KS], fz[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int i = i0 + k * BLOCK;
+    const bool ok = i < n;
+    const int ic = ok ? i : n - 1;
+    if (UNIFORM) { px[k] = ok ? x[ic] : far; py[k] = ok ? y[ic] : far; pz[k] = ok ? z[ic] : far; pm[k] = 0.0; }
+    else { px[k] = x[ic]; py[k] = y[ic]; pz[k] = z[ic]; pm[k] = ok ? m[ic] : 0.0; }   // padded sinks: zero mass, they push nothing
+    fx[k] = 0.0; fy[k] = 0.0; fz[k] = 0.0;
+  }
+  double e2 = eps2;
+  asm volatile("" : "+v"(e2));
+
+  for (int e = tid; e < WAVES * 3 * AS; e += BLOCK) (&acc[0][0][0])[e] = 0.0;
+
+  const int o_lo = o_begin + blockIdx.y * o_per_group;
+  const int o_hi = min(o_end, o_lo + o_per_group);
+  const int ntiles = max(0, o_hi - o_lo) * QT;
+  auto set_of = [&](int o) { const int d = o <= H ? o : nsets / 2; int c = b + d; return c >= nsets ? c - nsets : c; };
+
+  d4 stage[LPT];
+  auto fetch = [&](int T) {
+    const int c = set_of(o_lo + T / QT), q = T % QT;
+#pragma unroll
+    for (int l = 0; l < LPT; ++l) {
+      const int j = c * SET + q * TJ + l * BLOCK + tid;
+      const bool ok = j < n;
+      const int jc = ok ? j : n - 1;
+      stage[l] = UNIFORM ? d4{ok ? x[jc] : far, ok ? y[jc] : far, ok ? z[jc] : far, 0.0}
+                         : d4{x[jc], y[jc], z[jc], ok ? m[jc] : 0.0};
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int l = 0; l < LPT; ++l) tile[l * BLOCK + tid] = stage[l];
+    if (tid < 64) tile[TJ + tid] = stage[0];
+  };
+
+  if (ntiles > 0) { fetch(0); commit(); }
+#pragma unroll
+  for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(px[k]), "+v"(py[k]), "+v"(pz[k]), "+v"(pm[k]));
+  __syncthreads();
+
+  const d4* tl = tile + lane;
+  double* ac = &acc[wv][0][lane];
+
+  auto walk = [&](auto symtag) {
+    constexpr bool SYM = decltype(symtag)::value;
+    auto step = [&](const d4& s, d4& nx, int t) {
+      double gx = 0.0, gy = 0.0, gz = 0.0;
+      asm volatile("" ::: "memory");     // no LDS access may cross a step boundary (lane l reads what lane l + 1 wrote one step earlier)
+      nx = ld_src<UNIFORM>(tl + t + 1);
+      if (SYM) { gx = ac[0 * AS + t]; gy = ac[1 * AS + t]; gz = ac[2 * AS + t]; }
+      double dx[KS], dy[KS], dz[KS], f[KS];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        dx[k] = s.x - px[k]; dy[k] = s.y - py[k]; dz[k] = s.z - pz[k];
+        const double r2 = fma(dx[k], dx[k], fma(dy[k], dy[k], fma(dz[k], dz[k], e2)));
+        const double yv = __builtin_amdgcn_rsq(r2);
+        const double u = yv * yv;
+        const double q = fma(-r2, u, 5.0 / 3.0);
+        f[k] = (u * yv) * q;                         // (2/3) r^-3
+        if (GUARD) f[k] = r2 > e2 ? f[k] : 0.0;      // coincident pair at eps = 0: nothing
+        const double fi = UNIFORM ? f[k] : f[k] * s.w;
+        fx[k] = fma(fi, dx[k], fx[k]); fy[k] = fma(fi, dy[k], fy[k]); fz[k] = fma(fi, dz[k], fz[k]);
+      }
+      if (SYM) {
+        __builtin_amdgcn_sched_barrier(0);           // the source-side chains (which wait for the accumulator reads) stay behind the sink-side work
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const double fj = UNIFORM ? f[k] : f[k] * pm[k];
+          gx = fma(-fj, dx[k], gx); gy = fma(-fj, dy[k], gy); gz = fma(-fj, dz[k], gz);
+        }
+        ac[0 * AS + t] = gx; ac[1 * AS + t] = gy; ac[2 * AS + t] = gz;
+      }
+    };
+    d4 sa = ld_src<UNIFORM>(tl), sb;
+    for (int t = 0; t < TJ; t += 2) { step(sa, sb, t); step(sb, sa, t + 1); }
+  };
+
+  for (int T = 0; T < ntiles; ++T) {
+    const int o = o_lo + T / QT, q = T % QT;
+    const bool sym = o >= 1 && o <= H;
+    if (T + 1 < ntiles) fetch(T + 1);
+    if (sym) walk(std::true_type{}); else walk(std::false_type{});
+    __syncthreads();
+    if (sym) {
+      const int c = set_of(o);
+      double* sl = slab + (size_t)(o - max(o_begin, 1)) * 3 * n_pad + (size_t)c * SET + (size_t)q * TJ;
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+        for (int e = tid; e < TJ; e += BLOCK) {
+          double v = 0.0;
+#pragma unroll
+          for (int w2 = 0; w2 < WAVES; ++w2) { v += acc[w2][cc][e]; acc[w2][cc][e] = 0.0; }
+          if (e < 64) {
+#pragma unroll
+            for (int w2 = 0; w2 < WAVES; ++w2) { v += acc[w2][cc][TJ + e]; acc[w2][cc][TJ + e] = 0.0; }
+          }
+          sl[(size_t)cc * n_pad + e] = v;
+        }
+    }
+    if (T + 1 < ntiles) commit();
+    __syncthreads();
+  }
+
+  double* pp = part + (size_t)blockIdx.y * 3 * n_pad;
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int i = i0 + k * BLOCK;
+    if (i < n) { pp[i] = fx[k]; pp[n_pad + i] = fy[k]; pp[2 * n_pad + i] = fz[k]; }
+  }
+}
+
+// a[c][i] (+)= g * ( sum_y part[y][c][i] + sum_s slab[s][c][i] ), fixed order; several passes collect in `tot` first
+__global__ void __launch_bounds__(256)
+accel_sym_reduce_f64_kernel(const double* __restrict__ part, int ngroups, const double* __restrict__ slab, int nslots, int n, size_t n_pad,
+                            double G, const double* __restrict__ m0, double* __restrict__ tot, int first, int last,
+                            double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  for (int g = 0; g < ngroups; ++g) {
+    const double* p = part + (size_t)g * 3 * n_pad;
+    sx += p[i]; sy += p[n_pad + i]; sz += p[2 * n_pad + i];
+  }
+#pragma unroll 8
+  for (int s = 0; s < nslots; ++s) {
+    const double* p = slab + (size_t)s * 3 * n_pad;
+    sx += p[i]; sy += p[n_pad + i]; sz += p[2 * n_pad + i];
+  }
+  if (tot) {
+    if (!first) { sx += tot[i]; sy += tot[(size_t)n + i]; sz += tot[2 * (size_t)n + i]; }
+    if (!last) { tot[i] = sx; tot[(size_t)n + i] = sy; tot[2 * (size_t)n + i] = sz; return; }
+  }
+  const double g = F_SCALE * (m0 ? G * m0[0] : G);
+  double ox = g * sx, oy = g * sy, oz = g * sz;
+  if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
+  ax[i] = ox; ay[i] = oy; az[i] = oz;
+}
+
+long long env_ll(const char* name, long long dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoll(v) : dflt;
+}
+
+template <int KS>
+int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const double* m, int64_t n,
+            double eps2, double G, double* ax, double* ay, double* az, int flags, long long budget, long long env_groups) {
+  constexpr int TJ = 256, SET = BLOCK * KS;
+  const int nsets = (int)((n + SET - 1) / SET);
+  const size_t n_pad = (size_t)nsets * SET;
+  const int H = (nsets - 1) / 2;
+  const int n_o = H + 1 + (nsets % 2 == 0 ? 1 : 0);
+  const size_t slot_bytes = 3 * n_pad * sizeof(double);
+  int slots_per_pass = (int)std::max<long long>(1, budget / (long long)slot_bytes);
+  if (slots_per_pass > H) slots_per_pass = H > 0 ? H : 1;
+  const int npass = H > 0 ? (H + slots_per_pass - 1) / slots_per_pass : 1;
+  int groups_total = env_groups > 0 ? (int)env_groups : (4096 + nsets - 1) / nsets;
+  if (groups_total < 1) groups_total = 1;
+  if (groups_total > n_o) groups_total = n_o;
+  const int opg = (n_o + groups_total - 1) / groups_total;
+  const int max_groups_pass = (slots_per_pass + 2 + opg - 1) / opg + 1;
+  const size_t part_bytes = (size_t)max_groups_pass * 3 * n_pad * sizeof(double);
+  const size_t slab_bytes = (size_t)slots_per_pass * slot_bytes;
+  const size_t tot_bytes = npass > 1 ? 3 * (size_t)n * sizeof(double) : 0;
+  int rc = nb_ensure_work(c, part_bytes + slab_bytes + tot_bytes);
+  if (rc) return rc;
+  double* part = reinterpret_cast<double*>(c->work);
+  double* slab = reinterpret_cast<double*>(reinterpret_cast<char*>(c->work) + part_bytes);
+  double* tot = npass > 1 ? reinterpret_cast<double*>(reinterpret_cast<char*>(c->work) + part_bytes + slab_bytes) : nullptr;
+  const bool uniform = (flags & NB_UNIFORM_MASS) != 0;
+  const bool guard = !(eps2 > 0.0);
+  const int accumulate = flags & NB_ACCUMULATE;
+  for (int ps = 0; ps < npass; ++ps) {
+    const int s_begin = 1 + ps * slots_per_pass, s_end = 1 + std::min(H, (ps + 1) * slots_per_pass);
+    const int o_begin = ps == 0 ? 0 : s_begin;
+    const int o_end = (ps == npass - 1) ? n_o : s_end;
+    const int ngroups = (o_end - o_begin + opg - 1) / opg;
+    const int nslots = std::max(0, s_end - s_begin);
+    if (ngroups > max_groups_pass) return nb_fail(c, NB_ERR_ARG, "accel_sym_f64: internal group count");
+    dim3 grid(nsets, ngroups);
+#define NB_SYM_GO(GD, UF) accel_sym_f64_kernel<KS, TJ, GD, UF><<<grid, BLOCK, 0, c->stream>>>( \
+    x, y, z, m, (int)n, nsets, H, o_begin, o_end, opg, eps2, part, slab, n_pad)
+    if (guard) { if (uniform) NB_SYM_GO(true, true); else NB_SYM_GO(true, false); }
+    else       { if (uniform) NB_SYM_GO(false, true); else NB_SYM_GO(false, false); }
+#undef NB_SYM_GO
+    NB_HIP(c, hipGetLastError());
+    accel_sym_reduce_f64_kernel<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(part, ngroups, slab, nslots, (int)n, n_pad, G,
+                                                                                 uniform ? m : nullptr, tot, ps == 0, ps == npass - 1,
+                                                                                 ax, ay, az, accumulate);
+    NB_HIP(c, hipGetLastError());
+  }
+  return NB_OK;
+}
+
+}  // namespace
+
+// Self-interaction launch (sinks == sources); *taken = 0: not applicable (small n, switched off with NB_F64_SYM=0) — use the one-sided kernel
+int nb_launch_accel_sym_f64(nb_ctx* c, const double* x, const double* y, const double* z, const double* m, int64_t n,
+                            double eps2, double G, double* ax, double* ay, double* az, int flags, int* taken) {
+  *taken = 0;
+  static const long long mode = env_ll("NB_F64_SYM", 1), min_n = env_ll("NB_F64_SYM_MIN_N", 16384),
+                         budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_groups = env_ll("NB_F64_SYM_GROUPS", 0),
+                         env_ks = env_ll("NB_F64_SYM_KS", 0);
+  if (!mode || n < min_n || n >= (1ll << 31) || n <= BLOCK * 2) return NB_OK;
+  // sinks per lane: 8 for large n (N = 2^19, equal masses: 80.4 ms against 85.1 with 4 and 96.9 with 2; the one-sided kernel: 126.9), smaller
+  // sets for smaller n so that the launch still has a few thousand (set, offset) tiles
+  auto tiles = [&](int ks) { const long long ns = (n + BLOCK * ks - 1) / (BLOCK * ks); return ns * ((ns - 1) / 2 + 1); };
+  int ks = 8;
+  if (tiles(8) < 2500) ks = 4;
+  if (ks == 4 && tiles(4) < 2500) ks = 2;
+  if (env_ks == 2 || env_ks == 4 || env_ks == 8) ks = (int)env_ks;
+  const int rc = ks == 8 ? run_sym<8>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups)
+               : ks == 4 ? run_sym<4>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups)
+                         : run_sym<2>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups);
+  if (rc) return rc;
+  *taken = 1;
+  return NB_OK;
+}

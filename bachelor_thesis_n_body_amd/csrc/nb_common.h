@@ -72,6 +72,11 @@ int nb_ensure_work(nb_ctx* c, size_t bytes);
 int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, int64_t n_snk,
                         const float* xs, const float* ys, const float* zs, const float* ms, int64_t n_src,
                         float eps2, float G, float* ax, float* ay, float* az, int flags, double* phi = nullptr);
+// pair-symmetric self-interaction (sinks == sources, each unordered pair evaluated once); *taken = 0: not applicable, use the one-sided kernel
+int nb_launch_accel_sym_f32(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
+                            float eps2, float G, float* ax, float* ay, float* az, int flags, int* taken);
+int nb_launch_accel_sym_f64(nb_ctx* c, const double* x, const double* y, const double* z, const double* m, int64_t n,
+                            double eps2, double G, double* ax, double* ay, double* az, int flags, int* taken);
 int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const double* zi, int64_t n_snk,
                         const double* xs, const double* ys, const double* zs, const double* ms, int64_t n_src,
                         double eps2, double G, double* ax, double* ay, double* az, int flags, double* phi = nullptr);

@@ -102,7 +102,7 @@ def live_traffic(args, timeout_s=150):
             per = []
             for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "accel_f" in row["Kernel_Name"] and "reduce" not in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    if ("accel_f" in row["Kernel_Name"] or "accel_sym_f" in row["Kernel_Name"]) and "reduce" not in row["Kernel_Name"] and row["Counter_Name"] == counter:
                         per.append(float(row["Counter_Value"]))
             if not per:
                 return None, f"no {counter} rows for the accel kernel"

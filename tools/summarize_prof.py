@@ -12,7 +12,7 @@ print("== PMC (per dispatch of the dominant accel kernel; mean over its dispatch
 vals = defaultdict(list)
 for f in glob.glob(f"{out}/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "accel_f" in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"]:
+        if ("accel_f" in r["Kernel_Name"] or "accel_sym_f" in r["Kernel_Name"]) and "reduce" not in r["Kernel_Name"]:
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in vals.items()}
 for k in sorted(m):
