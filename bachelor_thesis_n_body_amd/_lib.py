@@ -37,6 +37,8 @@ SIGNATURES = {
     "nb_kdk_run": (_int, [_vp, _i64, _vp, _vp, _vp, _dbl, _dbl]),
     "nb_rung_step": (_int, [_vp, _int, _vp, _vp, _dbl, _dbl, _dbl, _dbl, C.POINTER(_i64)]),
     "nb_last_run_used_graph": (_int, [_vp]),
+    "nb_set_option": (_int, [_vp, _int, _i64]),
+    "nb_last_accel_symmetric": (_int, [_vp]),
     "nb_clock_probe_begin": (_int, [_int, _dbl, C.POINTER(_vp)]),
     "nb_clock_probe_stop": (_int, [_vp, _vp]),
     "nb_clock_probe_end": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_dbl)]),
@@ -49,6 +51,7 @@ SIGNATURES = {
     "nb_step_energy": (_int, [_vp, _dbl, _i64, _dbl, _dbl, _vp, _vp]),
     "nb_accel_dev": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _int]),
     "nb_accel_pot_dev": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp, _int]),
+    "nb_accel_pair_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
     "nb_pot_energy_dev": (_int, [_vp, _int, _vp, _vp, _i64, _dbl, _int, _vp]),
     "nb_potential_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _dbl, _vp, _int]),
     "nb_kinetic_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _i64, _vp]),

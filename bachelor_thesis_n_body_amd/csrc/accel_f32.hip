@@ -254,9 +254,10 @@ int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float
   const int accumulate = flags & NB_ACCUMULATE;
   const bool uniform = (flags & NB_UNIFORM_MASS) && n_src > 0;
   if (n_snk >= (1ll << 31) || n_src >= (1ll << 31)) return nb_fail(c, NB_ERR_ARG, "n must be < 2^31");
-  if (xi == xs && yi == ys && zi == zs && n_snk == n_src && !phi) {   // a set on itself: every unordered pair once (accel_sym_f32.hip)
+  c->last_accel_sym = false;
+  if (xi == xs && yi == ys && zi == zs && n_snk == n_src) {   // a set on itself: every unordered pair once (accel_sym_f32.hip)
     int taken = 0;
-    const int rc = nb_launch_accel_sym_f32(c, xs, ys, zs, ms, n_src, eps2, G, ax, ay, az, flags, &taken);
+    const int rc = nb_launch_accel_sym_f32(c, xs, ys, zs, ms, n_src, eps2, G, ax, ay, az, flags, phi, &taken);
     if (rc || taken) return rc;
   }
   constexpr int TILE = 512;

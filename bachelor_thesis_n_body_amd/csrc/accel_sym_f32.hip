@@ -46,12 +46,18 @@ template <bool UNIFORM> __device__ inline float4 ld_src(const float4* p) {
 
 // Offsets of this launch are numbered o = 0 .. : o = 0 -> d = 0 (one-sided), o = 1 .. H -> d = o (two-sided), o = H + 1 -> d = nsets / 2
 // (one-sided; only when nsets is even). Block (b, y) walks o in [o_begin + y * o_per_group, ...) capped at o_end.
-template <int KS, int U, int TJ, bool GUARD, bool UNIFORM>
+template <int KS, int U, int TJ, bool GUARD, bool UNIFORM, bool POT>
 __global__ void __launch_bounds__(BLOCK)
 accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ m,
-                     int n, int nsets, int H, int o_begin, int o_end, int o_per_group, int slot0, float eps2,
-                     double* __restrict__ part, float* __restrict__ slab, size_t n_pad) {
+                     int n, int nsets, int H, int o_begin, int o_end, int o_per_group, float eps2,
+                     double* __restrict__ part, float* __restrict__ slab, size_t n_pad,
+                     const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs, const float* __restrict__ ms,
+                     int n_src, int nsets_src, size_t n_pad_src, int cross, int b0) {
+  // cross = 0: the set (x, y, z, m) on itself (xs.. are the same arrays). cross = 1: block A = (x..) against a DIFFERENT block B = (xs..):
+  // sink set b of A walks every set of B two-sidedly (o = 0 .. nsets_src - 1 -> set (b + o) mod nsets_src); B's sums go to slab slot
+  // blockIdx.x (one slot per sink set of this launch, which covers the sink sets b0 .. b0 + gridDim.x - 1).
   static_assert(KS % 2 == 0 && TJ % BLOCK == 0 && TJ % U == 0, "shape");
+  constexpr int NC = POT ? 4 : 3;    // POT: the pair potential m / sqrt(r^2 + eps^2) rides along as a fourth component on both sides
   constexpr int SET = BLOCK * KS;
   constexpr int KP = KS / 2;
   constexpr int AS = TJ + 64;        // tile entries incl. the 64 wrap-around copies
@@ -59,10 +65,10 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
   constexpr int QT = SET / TJ;       // tiles per set
   __shared__ float4 tile[AS];
   constexpr int AW = 2;              // the two halves of a packed partial sum keep separate accumulators (no add per step)
-  __shared__ float acc[WAVES][3][AS * AW];
+  __shared__ float acc[WAVES][NC][AS * AW];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int b = blockIdx.x;
+  const int b = b0 + blockIdx.x;
   const int i0 = b * SET + tid;
   const float far = 1e20f;           // UNIFORM padding: r^2 overflows to +inf, v_rsq_f32(+inf) = +0, every term exactly 0
 
@@ -80,19 +86,22 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
       pm[p] = v2f{oa ? m[ca] : 0.f, ob ? m[cb] : 0.f};
     }
   }
-  double tx[KS], ty[KS], tz[KS];
+  double tx[KS], ty[KS], tz[KS], tp[KS];
 #pragma unroll
-  for (int k = 0; k < KS; ++k) { tx[k] = 0.0; ty[k] = 0.0; tz[k] = 0.0; }
+  for (int k = 0; k < KS; ++k) { tx[k] = 0.0; ty[k] = 0.0; tz[k] = 0.0; tp[k] = 0.0; }
   v2f e2;
   asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2" : "=v"(e2.x), "=v"(e2.y) : "s"(eps2));
 
-  for (int e = tid; e < WAVES * 3 * AS * AW; e += BLOCK) (&acc[0][0][0])[e] = 0.f;
+  for (int e = tid; e < WAVES * NC * AS * AW; e += BLOCK) (&acc[0][0][0])[e] = 0.f;
 
   const int o_lo = o_begin + blockIdx.y * o_per_group;
   const int o_hi = min(o_end, o_lo + o_per_group);
   const int ntiles = max(0, o_hi - o_lo) * QT;
 
-  auto set_of = [&](int o) { const int d = o <= H ? o : nsets / 2; int c = b + d; return c >= nsets ? c - nsets : c; };
+  auto set_of = [&](int o) {
+    if (cross) return (b + o) % nsets_src;
+    const int d = o <= H ? o : nsets / 2; int c = b + d; return c >= nsets ? c - nsets : c;
+  };
 
   float4 stage[LPT];
   auto fetch = [&](int T) {
@@ -100,10 +109,10 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
       const int j = c * SET + q * TJ + l * BLOCK + tid;
-      const bool ok = j < n;
-      const int jc = ok ? j : n - 1;
-      stage[l] = UNIFORM ? make_float4(ok ? x[jc] : far, ok ? y[jc] : far, ok ? z[jc] : far, 0.0f)
-                         : make_float4(x[jc], y[jc], z[jc], ok ? m[jc] : 0.0f);
+      const bool ok = j < n_src;
+      const int jc = ok ? j : n_src - 1;
+      stage[l] = UNIFORM ? make_float4(ok ? xs[jc] : far, ok ? ys[jc] : far, ok ? zs[jc] : far, 0.0f)
+                         : make_float4(xs[jc], ys[jc], zs[jc], ok ? ms[jc] : 0.0f);
     }
   };
   auto commit = [&]() {
@@ -122,16 +131,16 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
 
   auto walk = [&](auto symtag) {
     constexpr bool SYM = decltype(symtag)::value;
-    v2f fx[KP], fy[KP], fz[KP];
+    v2f fx[KP], fy[KP], fz[KP], fp[KP];
 #pragma unroll
-    for (int p = 0; p < KP; ++p) { fx[p] = v2f{0.f, 0.f}; fy[p] = v2f{0.f, 0.f}; fz[p] = v2f{0.f, 0.f}; }
+    for (int p = 0; p < KP; ++p) { fx[p] = v2f{0.f, 0.f}; fy[p] = v2f{0.f, 0.f}; fz[p] = v2f{0.f, 0.f}; fp[p] = v2f{0.f, 0.f}; }
     // step t: lane l meets the sources t + u * TJ/U + l (u < U) — 64 different sources per instruction, and the U sets of a step are disjoint.
     // The sources of step t + 1 are read during step t into the other of two register sets (the tile has 64 entries beyond the last
     // step's); the accumulators of a step are read at its top and consumed at its end (the scheduler may not pull the source-side
     // chains above the sink-side work), so no LDS round trip is exposed.
     constexpr int HS = TJ / U;
     auto step = [&](float4 (&s)[U], float4 (&nx)[U], int t) {
-      v2f gx[U], gy[U], gz[U];
+      v2f gx[U], gy[U], gz[U], gp[U];
       // lane l reads the accumulator lane l + 1 wrote one step earlier (same wave: LDS operations complete in program order); the
       // compiler sees only this lane's addresses, so no LDS access may be moved across a step boundary
       asm volatile("" ::: "memory");
@@ -145,9 +154,10 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
           gx[u] = *reinterpret_cast<const v2f*>(ac + (0 * AS + t + u * HS) * 2);
           gy[u] = *reinterpret_cast<const v2f*>(ac + (1 * AS + t + u * HS) * 2);
           gz[u] = *reinterpret_cast<const v2f*>(ac + (2 * AS + t + u * HS) * 2);
+          if (POT) gp[u] = *reinterpret_cast<const v2f*>(ac + (3 * AS + t + u * HS) * 2);
         }
       }
-      v2f dx[U][KP], dy[U][KP], dz[U][KP], r2[U][KP], rinv[U][KP], r3[U][KP];
+      v2f dx[U][KP], dy[U][KP], dz[U][KP], r2[U][KP], rinv[U][KP], fj[U][KP], pj[U][KP];
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -175,11 +185,16 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
       for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int p = 0; p < KP; ++p) {
-          r3[u][p] = (rinv[u][p] * rinv[u][p]) * rinv[u][p];
-          const v2f fi = UNIFORM ? r3[u][p] : r3[u][p] * v2f{s[u].w, s[u].w};      // factor of the sinks' sums: m_j / r^3
+          // factors of the sinks' sums (m_j / r^3, m_j / r) and of the source's sums (m_i / r^3, m_i / r); equal masses: applied at the end
+          const v2f rinv2 = rinv[u][p] * rinv[u][p];
+          v2f fi, pi;
+          if (UNIFORM) { fi = rinv2 * rinv[u][p]; fj[u][p] = fi; pi = rinv[u][p]; pj[u][p] = pi; }
+          else if (POT) { pi = rinv[u][p] * v2f{s[u].w, s[u].w}; pj[u][p] = rinv[u][p] * pm[p]; fi = pi * rinv2; fj[u][p] = pj[u][p] * rinv2; }
+          else { const v2f r3 = rinv2 * rinv[u][p]; fi = r3 * v2f{s[u].w, s[u].w}; fj[u][p] = r3 * pm[p]; }
           fx[p] = __builtin_elementwise_fma(fi, dx[u][p], fx[p]);
           fy[p] = __builtin_elementwise_fma(fi, dy[u][p], fy[p]);
           fz[p] = __builtin_elementwise_fma(fi, dz[u][p], fz[p]);
+          if (POT) fp[p] = fp[p] + pi;
         }
       if (SYM) {
         __builtin_amdgcn_sched_barrier(0);
@@ -187,16 +202,17 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
         for (int u = 0; u < U; ++u)
 #pragma unroll
           for (int p = 0; p < KP; ++p) {                                   // a_j -= fj (r_j - r_i)
-            const v2f fj = UNIFORM ? r3[u][p] : r3[u][p] * pm[p];        // factor of the source's sum: m_i / r^3
-            gx[u] = __builtin_elementwise_fma(-fj, dx[u][p], gx[u]);
-            gy[u] = __builtin_elementwise_fma(-fj, dy[u][p], gy[u]);
-            gz[u] = __builtin_elementwise_fma(-fj, dz[u][p], gz[u]);
+            gx[u] = __builtin_elementwise_fma(-fj[u][p], dx[u][p], gx[u]);
+            gy[u] = __builtin_elementwise_fma(-fj[u][p], dy[u][p], gy[u]);
+            gz[u] = __builtin_elementwise_fma(-fj[u][p], dz[u][p], gz[u]);
+            if (POT) gp[u] = gp[u] + pj[u][p];
           }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           *reinterpret_cast<v2f*>(ac + (0 * AS + t + u * HS) * 2) = gx[u];
           *reinterpret_cast<v2f*>(ac + (1 * AS + t + u * HS) * 2) = gy[u];
           *reinterpret_cast<v2f*>(ac + (2 * AS + t + u * HS) * 2) = gz[u];
+          if (POT) *reinterpret_cast<v2f*>(ac + (3 * AS + t + u * HS) * 2) = gp[u];
         }
       }
     };
@@ -209,20 +225,21 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
     for (int p = 0; p < KP; ++p) {
       tx[2 * p] += (double)fx[p].x; ty[2 * p] += (double)fy[p].x; tz[2 * p] += (double)fz[p].x;
       tx[2 * p + 1] += (double)fx[p].y; ty[2 * p + 1] += (double)fy[p].y; tz[2 * p + 1] += (double)fz[p].y;
+      if (POT) { tp[2 * p] += (double)fp[p].x; tp[2 * p + 1] += (double)fp[p].y; }
     }
   };
 
   for (int T = 0; T < ntiles; ++T) {
     const int o = o_lo + T / QT, q = T % QT;
-    const bool sym = o >= 1 && o <= H;
+    const bool sym = cross || (o >= 1 && o <= H);
     if (T + 1 < ntiles) fetch(T + 1);
     if (sym) walk(std::true_type{}); else walk(std::false_type{});
     __syncthreads();                                   // every wave has finished the tile: accumulators complete, tile free
     if (sym) {
       const int c = set_of(o);
-      float* sl = slab + (size_t)(slot0 + o - max(o_begin, 1)) * 3 * n_pad + (size_t)c * SET + (size_t)q * TJ;
+      float* sl = slab + (size_t)(cross ? (int)blockIdx.x : o - max(o_begin, 1)) * NC * n_pad_src + (size_t)c * SET + (size_t)q * TJ;
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc)
+      for (int cc = 0; cc < NC; ++cc)
         for (int e = tid; e < TJ; e += BLOCK) {
           float v = 0.f;
 #pragma unroll
@@ -235,18 +252,18 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
 #pragma unroll
               for (int h = 0; h < AW; ++h) { v += acc[w2][cc][(TJ + e) * AW + h]; acc[w2][cc][(TJ + e) * AW + h] = 0.f; }
           }
-          sl[(size_t)cc * n_pad + e] = v;
+          sl[(size_t)cc * n_pad_src + e] = v;
         }
     }
     if (T + 1 < ntiles) commit();
     __syncthreads();
   }
 
-  double* pp = part + (size_t)blockIdx.y * 3 * n_pad;
+  double* pp = part + (size_t)blockIdx.y * NC * n_pad;
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
     const int i = i0 + k * BLOCK;
-    if (i < n) { pp[i] = tx[k]; pp[n_pad + i] = ty[k]; pp[2 * n_pad + i] = tz[k]; }
+    if (i < n) { pp[i] = tx[k]; pp[n_pad + i] = ty[k]; pp[2 * n_pad + i] = tz[k]; if (POT) pp[3 * n_pad + i] = tp[k]; }
   }
 }
 
@@ -255,23 +272,28 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
 __global__ void __launch_bounds__(256)
 accel_sym_reduce_f32_kernel(const double* __restrict__ part, int ngroups, const float* __restrict__ slab, int nslots, int n, size_t n_pad,
                             float G, const float* __restrict__ m0, double* __restrict__ tot, int first, int last,
-                            float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+                            float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, int accumulate, double* __restrict__ phi,
+                            int i_begin) {
+  const int nc = phi ? 4 : 3;
+  const int i = i_begin + blockIdx.x * blockDim.x + threadIdx.x;      // particles [i_begin, n)
   if (i >= n) return;
-  double sx = 0.0, sy = 0.0, sz = 0.0;
+  double sx = 0.0, sy = 0.0, sz = 0.0, sp = 0.0;
   for (int g = 0; g < ngroups; ++g) {
-    const double* p = part + (size_t)g * 3 * n_pad;
+    const double* p = part + (size_t)g * nc * n_pad;
     sx += p[i]; sy += p[n_pad + i]; sz += p[2 * n_pad + i];
+    if (phi) sp += p[3 * n_pad + i];
   }
 #pragma unroll 8
   for (int s = 0; s < nslots; ++s) {
-    const float* p = slab + (size_t)s * 3 * n_pad;
+    const float* p = slab + (size_t)s * nc * n_pad;
     sx += (double)p[i]; sy += (double)p[n_pad + i]; sz += (double)p[2 * n_pad + i];
+    if (phi) sp += (double)p[3 * n_pad + i];
   }
   if (tot) {
-    if (!first) { sx += tot[i]; sy += tot[(size_t)n + i]; sz += tot[2 * (size_t)n + i]; }
-    if (!last) { tot[i] = sx; tot[(size_t)n + i] = sy; tot[2 * (size_t)n + i] = sz; return; }
+    if (!first) { sx += tot[i]; sy += tot[(size_t)n + i]; sz += tot[2 * (size_t)n + i]; if (phi) sp += tot[3 * (size_t)n + i]; }
+    if (!last) { tot[i] = sx; tot[(size_t)n + i] = sy; tot[2 * (size_t)n + i] = sz; if (phi) tot[3 * (size_t)n + i] = sp; return; }
   }
+  if (phi) { const double ph = (m0 ? (double)m0[0] : 1.0) * sp; phi[i] = accumulate ? phi[i] + ph : ph; }   // per unit G, self term included
   const double g = m0 ? (double)G * (double)m0[0] : (double)G;
   float ox = (float)(g * sx), oy = (float)(g * sy), oz = (float)(g * sz);
   if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
@@ -283,15 +305,15 @@ long long env_ll(const char* name, long long dflt) {
   return v && *v ? atoll(v) : dflt;
 }
 
-template <int KS, int U>
+template <int KS, int U, bool POT>
 int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
-            float eps2, float G, float* ax, float* ay, float* az, int flags, long long budget, long long env_groups) {
-  constexpr int TJ = 512, SET = BLOCK * KS;
+            float eps2, float G, float* ax, float* ay, float* az, int flags, long long budget, long long env_groups, double* phi) {
+  constexpr int TJ = POT ? 256 : 512, SET = BLOCK * KS, NC = POT ? 4 : 3;   // POT: a fourth accumulator per source — half the tile keeps the LDS footprint
   const int nsets = (int)((n + SET - 1) / SET);
   const size_t n_pad = (size_t)nsets * SET;
   const int H = (nsets - 1) / 2;
   const int n_o = H + 1 + (nsets % 2 == 0 ? 1 : 0);          // offsets incl. the one-sided ones
-  const size_t slot_bytes = 3 * n_pad * sizeof(float);
+  const size_t slot_bytes = NC * n_pad * sizeof(float);
   int slots_per_pass = (int)std::max<long long>(1, budget / (long long)slot_bytes);
   if (slots_per_pass > H) slots_per_pass = H > 0 ? H : 1;
   // pass 0 takes o = 0 and the first two-sided offsets, the last pass also the one-sided half offset
@@ -302,9 +324,9 @@ int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const flo
   if (groups_total > n_o) groups_total = n_o;
   const int opg = (n_o + groups_total - 1) / groups_total;   // offsets per group
   const int max_groups_pass = (slots_per_pass + 2 + opg - 1) / opg + 1;
-  const size_t part_bytes = (size_t)max_groups_pass * 3 * n_pad * sizeof(double);
+  const size_t part_bytes = (size_t)max_groups_pass * NC * n_pad * sizeof(double);
   const size_t slab_bytes = (size_t)slots_per_pass * slot_bytes;
-  const size_t tot_bytes = npass > 1 ? 3 * (size_t)n * sizeof(double) : 0;
+  const size_t tot_bytes = npass > 1 ? NC * (size_t)n * sizeof(double) : 0;
   int rc = nb_ensure_work(c, part_bytes + slab_bytes + tot_bytes);
   if (rc) return rc;
   double* part = reinterpret_cast<double*>(c->work);
@@ -322,8 +344,8 @@ int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const flo
     const int nslots = std::max(0, s_end - s_begin);
     if (ngroups > max_groups_pass) return nb_fail(c, NB_ERR_ARG, "accel_sym_f32: internal group count");
     dim3 grid(nsets, ngroups);
-#define NB_SYM_GO(GD, UF) accel_sym_f32_kernel<KS, U, TJ, GD, UF><<<grid, BLOCK, 0, c->stream>>>( \
-    x, y, z, m, (int)n, nsets, H, o_begin, o_end, opg, 0, eps2, part, slab, n_pad)
+#define NB_SYM_GO(GD, UF) accel_sym_f32_kernel<KS, U, TJ, GD, UF, POT><<<grid, BLOCK, 0, c->stream>>>( \
+    x, y, z, m, (int)n, nsets, H, o_begin, o_end, opg, eps2, part, slab, n_pad, x, y, z, m, (int)n, nsets, n_pad, 0, 0)
     if constexpr (KS == 12) {            // equal masses only
       if (guard) NB_SYM_GO(true, true); else NB_SYM_GO(false, true);
     } else {
@@ -334,7 +356,58 @@ int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const flo
     NB_HIP(c, hipGetLastError());
     accel_sym_reduce_f32_kernel<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(part, ngroups, slab, nslots, (int)n, n_pad, G,
                                                                                  uniform ? m : nullptr, tot, ps == 0, ps == npass - 1,
-                                                                                 ax, ay, az, accumulate);
+                                                                                 ax, ay, az, accumulate, phi, 0);
+    NB_HIP(c, hipGetLastError());
+  }
+  return NB_OK;
+}
+
+// Block A (sinks that stay: accelerations += / = into aax..) against a different block B (accelerations due to A written to bax..): every
+// A-B pair evaluated once. Several passes over ranges of A's sets when the slab [sets of A][NC][n_b] exceeds the scratch budget.
+template <int KS, int U, bool POT>
+int run_cross(nb_ctx* c, const float* xa, const float* ya, const float* za, const float* ma, int64_t na,
+              const float* xb, const float* yb, const float* zb, const float* mb, int64_t nb,
+              float eps2, float G, float* aax, float* aay, float* aaz, float* bax, float* bay, float* baz,
+              double* phi_a, double* phi_b, int flags, long long budget) {
+  constexpr int TJ = POT ? 256 : 512, SET = BLOCK * KS, NC = POT ? 4 : 3;
+  const int nsa = (int)((na + SET - 1) / SET), nsb = (int)((nb + SET - 1) / SET);
+  const size_t npa = (size_t)nsa * SET, npb = (size_t)nsb * SET;
+  const size_t slot_bytes = NC * npb * sizeof(float);
+  int sets_per_pass = (int)std::max<long long>(1, budget / (long long)slot_bytes);
+  if (sets_per_pass > nsa) sets_per_pass = nsa;
+  int groups = (4096 + sets_per_pass - 1) / sets_per_pass;                  // ~4096 blocks per launch
+  if (groups > nsb) groups = nsb;
+  if (groups < 1) groups = 1;
+  const int opg = (nsb + groups - 1) / groups;
+  groups = (nsb + opg - 1) / opg;
+  const size_t part_bytes = (size_t)groups * NC * npa * sizeof(double);
+  int rc = nb_ensure_work(c, part_bytes + (size_t)sets_per_pass * slot_bytes);
+  if (rc) return rc;
+  double* part = reinterpret_cast<double*>(c->work);
+  float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(c->work) + part_bytes);
+  const bool uniform = (flags & NB_UNIFORM_MASS) != 0;
+  const bool guard = !(eps2 >= 1e-20f);
+  for (int b0 = 0; b0 < nsa; b0 += sets_per_pass) {
+    const int nb_sets = std::min(sets_per_pass, nsa - b0);
+    dim3 grid(nb_sets, groups);
+#define NB_SYM_GO(GD, UF) accel_sym_f32_kernel<KS, U, TJ, GD, UF, POT><<<grid, BLOCK, 0, c->stream>>>( \
+    xa, ya, za, ma, (int)na, nsa, 0, 0, nsb, opg, eps2, part, slab, npa, xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0)
+    if constexpr (KS == 12) {
+      if (guard) NB_SYM_GO(true, true); else NB_SYM_GO(false, true);
+    } else {
+      if (guard) { if (uniform) NB_SYM_GO(true, true); else NB_SYM_GO(true, false); }
+      else       { if (uniform) NB_SYM_GO(false, true); else NB_SYM_GO(false, false); }
+    }
+#undef NB_SYM_GO
+    NB_HIP(c, hipGetLastError());
+    // A's sinks of this pass: complete after it
+    const int i_begin = b0 * SET, i_end = (int)std::min<int64_t>(na, (int64_t)(b0 + nb_sets) * SET);
+    accel_sym_reduce_f32_kernel<<<(i_end - i_begin + 255) / 256, 256, 0, c->stream>>>(part, groups, nullptr, 0, i_end, npa, G, uniform ? ma : nullptr,
+                                                                                       nullptr, 1, 1, aax, aay, aaz, flags & NB_ACCUMULATE, phi_a, i_begin);
+    NB_HIP(c, hipGetLastError());
+    // B's sums: this pass' slots, added to what earlier passes left
+    accel_sym_reduce_f32_kernel<<<(int)((nb + 255) / 256), 256, 0, c->stream>>>(nullptr, 0, slab, nb_sets, (int)nb, npb, G, uniform ? ma : nullptr,
+                                                                                 nullptr, 1, 1, bax, bay, baz, b0 > 0, phi_b, 0);
     NB_HIP(c, hipGetLastError());
   }
   return NB_OK;
@@ -343,26 +416,58 @@ int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const flo
 }  // namespace
 
 // Self-interaction launch (sinks == sources). Returns NB_OK and sets *taken = 1 when the pair-symmetric kernel ran, *taken = 0 when the
-// caller should use the one-sided kernel (small n, fused potential, switched off with NB_F32_SYM=0).
+// caller should use the one-sided kernel (small n, switched off with NB_F32_SYM=0). phi non-null: the fused potential (per unit G, self term included).
 int nb_launch_accel_sym_f32(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
-                            float eps2, float G, float* ax, float* ay, float* az, int flags, int* taken) {
+                            float eps2, float G, float* ax, float* ay, float* az, int flags, double* phi, int* taken) {
   *taken = 0;
-  static const long long mode = env_ll("NB_F32_SYM", 1), min_n = env_ll("NB_F32_SYM_MIN_N", 32768),
-                         budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_groups = env_ll("NB_F32_SYM_GROUPS", 0);
+  c->last_accel_sym = false;
+  static const long long env_mode = env_ll("NB_F32_SYM", 1), env_min_n = env_ll("NB_F32_SYM_MIN_N", 32768),
+                         env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_groups = env_ll("NB_F32_SYM_GROUPS", 0),
+                         env_ks = env_ll("NB_F32_SYM_KS", 0);
+  const long long mode = c->sym_enable >= 0 ? c->sym_enable : env_mode, min_n = c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
+                  budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
   if (!mode || n < min_n || n >= (1ll << 31) || n <= BLOCK * 4) return NB_OK;
   // Sinks per lane (set = 256 * KS particles). Equal masses, large n: 12 sinks x 1 source per step (244 VGPRs; fewest accumulator round trips
   // per pair: 159.6 ms at N = 2^20 against 163.7 with 8 sinks x 2 sources, one box); per-particle masses carry two more registers per sink
   // pair: 8 x 2. Smaller n: smaller sets, so that the launch still has a few thousand (set, offset) tiles to spread over 256 CUs.
   auto tiles = [&](int ks) { const long long ns = (n + BLOCK * ks - 1) / (BLOCK * ks); return ns * ((ns - 1) / 2 + 1); };
-  static const long long env_ks = env_ll("NB_F32_SYM_KS", 0);
-  int ks = (flags & NB_UNIFORM_MASS) ? 12 : 8;
+  int ks = (flags & NB_UNIFORM_MASS) && !phi ? 12 : 8;
   if (ks == 12 && tiles(12) < 2500) ks = 8;
   if (ks == 8 && tiles(8) < 2500) ks = 4;
-  if (env_ks == 4 || env_ks == 8 || (env_ks == 12 && (flags & NB_UNIFORM_MASS))) ks = (int)env_ks;
-  const int rc = ks == 12 ? run_sym<12, 1>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups)
-               : ks == 8  ? run_sym<8, 2>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups)
-                          : run_sym<4, 2>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups);
+  if (env_ks == 4 || env_ks == 8 || (env_ks == 12 && (flags & NB_UNIFORM_MASS) && !phi)) ks = (int)env_ks;
+#define NB_RUN(K, UU, PT) run_sym<K, UU, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups, phi)
+  const int rc = phi ? (ks == 8 ? NB_RUN(8, 1, true) : NB_RUN(4, 2, true))
+                     : (ks == 12 ? NB_RUN(12, 1, false) : ks == 8 ? NB_RUN(8, 2, false) : NB_RUN(4, 2, false));
+#undef NB_RUN
   if (rc) return rc;
   *taken = 1;
+  c->last_accel_sym = true;
+  return NB_OK;
+}
+
+// Two different blocks, every A-B pair once: A's accelerations (+)= the force of B, B's accelerations (bax..) = the force of A (overwritten).
+// *taken = 0: not applicable (small blocks, switched off) — the caller runs the one-sided kernel in both directions.
+int nb_launch_accel_cross_f32(nb_ctx* c, const float* xa, const float* ya, const float* za, const float* ma, int64_t na,
+                              const float* xb, const float* yb, const float* zb, const float* mb, int64_t nb,
+                              float eps2, float G, float* aax, float* aay, float* aaz, float* bax, float* bay, float* baz,
+                              double* phi_a, double* phi_b, int flags, int* taken) {
+  *taken = 0;
+  static const long long env_mode = env_ll("NB_F32_SYM", 1), env_min_n = env_ll("NB_F32_SYM_MIN_N", 32768), env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30);
+  const long long mode = c->sym_enable >= 0 ? c->sym_enable : env_mode, min_n = c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
+                  budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
+  const int64_t nmin = std::min(na, nb);
+  if (!mode || nmin * 2 < min_n || na >= (1ll << 31) || nb >= (1ll << 31) || nmin < 1) return NB_OK;   // (na x nb pairs ~ a self launch of sqrt(2 na nb))
+  auto tiles = [&](int ks) { const long long sa = (na + BLOCK * ks - 1) / (BLOCK * ks), sb = (nb + BLOCK * ks - 1) / (BLOCK * ks); return sa * sb; };
+  const bool pot = phi_a != nullptr;
+  int ks = (flags & NB_UNIFORM_MASS) && !pot ? 12 : 8;
+  if (ks == 12 && tiles(12) < 2500) ks = 8;
+  if (ks == 8 && tiles(8) < 2500) ks = 4;
+#define NB_RUN(K, UU, PT) run_cross<K, UU, PT>(c, xa, ya, za, ma, na, xb, yb, zb, mb, nb, eps2, G, aax, aay, aaz, bax, bay, baz, phi_a, phi_b, flags, budget)
+  const int rc = pot ? (ks == 8 ? NB_RUN(8, 1, true) : NB_RUN(4, 2, true))
+                     : (ks == 12 ? NB_RUN(12, 1, false) : ks == 8 ? NB_RUN(8, 2, false) : NB_RUN(4, 2, false));
+#undef NB_RUN
+  if (rc) return rc;
+  *taken = 1;
+  c->last_accel_sym = true;
   return NB_OK;
 }

@@ -22,6 +22,7 @@ namespace {
 
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
+constexpr double P_SCALE = 0.5;     // and the 1/2 of the potential's (r^-1 = y (3 - r2 y^2) / 2)
 constexpr double F_SCALE = 1.5;     // the 3/2 of the first-order rsqrt refinement, applied with G in the epilogue (see accel_f64.hip)
 struct alignas(16) d4 { double x, y, z, w; };
 struct alignas(16) d3 { double x, y, z; };
@@ -31,26 +32,31 @@ template <bool UNIFORM> __device__ inline d4 ld_src(const d4* p) {
   return *p;
 }
 
-template <int KS, int TJ, bool GUARD, bool UNIFORM>
+template <int KS, int TJ, bool GUARD, bool UNIFORM, bool POT>
 __global__ void __launch_bounds__(BLOCK)
 accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z, const double* __restrict__ m,
                      int n, int nsets, int H, int o_begin, int o_end, int o_per_group, double eps2,
-                     double* __restrict__ part, double* __restrict__ slab, size_t n_pad) {
+                     double* __restrict__ part, double* __restrict__ slab, size_t n_pad,
+                     const double* __restrict__ xs, const double* __restrict__ ys, const double* __restrict__ zs, const double* __restrict__ ms,
+                     int n_src, int nsets_src, size_t n_pad_src, int cross, int b0) {
+  // cross = 0: the set on itself (xs.. are the same arrays); cross = 1: block A = (x..) against a different block B = (xs..), every A-B pair
+  // two-sided, B's sums to slab slot blockIdx.x (see accel_sym_f32.hip)
   static_assert(TJ % BLOCK == 0 && TJ % 2 == 0, "shape");
   constexpr int SET = BLOCK * KS;
   constexpr int AS = TJ + 64;
   constexpr int LPT = TJ / BLOCK;
   constexpr int QT = SET / TJ;
   static_assert(SET % TJ == 0, "a set is a whole number of tiles");
+  constexpr int NC = POT ? 4 : 3;    // POT: the pair potential rides along as a fourth component on both sides
   __shared__ d4 tile[AS];
-  __shared__ double acc[WAVES][3][AS];
+  __shared__ double acc[WAVES][NC][AS];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int b = blockIdx.x;
+  const int b = b0 + blockIdx.x;
   const int i0 = b * SET + tid;
   const double far = 1e150;          // UNIFORM padding: y = r2^-1/2 ~ 1e-150, y^3 underflows to exactly 0
 
-  double px[KS], py[KS], pz[KS], pm[KS], fx[KS], fy[KS], fz[KS];
+  double px[KS], py[KS], pz[KS], pm[KS], fx[KS], fy[KS], fz[KS], fp[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
     const int i = i0 + k * BLOCK;
@@ -58,17 +64,20 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
     const int ic = ok ? i : n - 1;
     if (UNIFORM) { px[k] = ok ? x[ic] : far; py[k] = ok ? y[ic] : far; pz[k] = ok ? z[ic] : far; pm[k] = 0.0; }
     else { px[k] = x[ic]; py[k] = y[ic]; pz[k] = z[ic]; pm[k] = ok ? m[ic] : 0.0; }   // padded sinks: zero mass, they push nothing
-    fx[k] = 0.0; fy[k] = 0.0; fz[k] = 0.0;
+    fx[k] = 0.0; fy[k] = 0.0; fz[k] = 0.0; fp[k] = 0.0;
   }
   double e2 = eps2;
   asm volatile("" : "+v"(e2));
 
-  for (int e = tid; e < WAVES * 3 * AS; e += BLOCK) (&acc[0][0][0])[e] = 0.0;
+  for (int e = tid; e < WAVES * NC * AS; e += BLOCK) (&acc[0][0][0])[e] = 0.0;
 
   const int o_lo = o_begin + blockIdx.y * o_per_group;
   const int o_hi = min(o_end, o_lo + o_per_group);
   const int ntiles = max(0, o_hi - o_lo) * QT;
-  auto set_of = [&](int o) { const int d = o <= H ? o : nsets / 2; int c = b + d; return c >= nsets ? c - nsets : c; };
+  auto set_of = [&](int o) {
+    if (cross) return (b + o) % nsets_src;
+    const int d = o <= H ? o : nsets / 2; int c = b + d; return c >= nsets ? c - nsets : c;
+  };
 
   d4 stage[LPT];
   auto fetch = [&](int T) {
@@ -76,10 +85,10 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
       const int j = c * SET + q * TJ + l * BLOCK + tid;
-      const bool ok = j < n;
-      const int jc = ok ? j : n - 1;
-      stage[l] = UNIFORM ? d4{ok ? x[jc] : far, ok ? y[jc] : far, ok ? z[jc] : far, 0.0}
-                         : d4{x[jc], y[jc], z[jc], ok ? m[jc] : 0.0};
+      const bool ok = j < n_src;
+      const int jc = ok ? j : n_src - 1;
+      stage[l] = UNIFORM ? d4{ok ? xs[jc] : far, ok ? ys[jc] : far, ok ? zs[jc] : far, 0.0}
+                         : d4{xs[jc], ys[jc], zs[jc], ok ? ms[jc] : 0.0};
     }
   };
   auto commit = [&]() {
@@ -99,11 +108,11 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
   auto walk = [&](auto symtag) {
     constexpr bool SYM = decltype(symtag)::value;
     auto step = [&](const d4& s, d4& nx, int t) {
-      double gx = 0.0, gy = 0.0, gz = 0.0;
+      double gx = 0.0, gy = 0.0, gz = 0.0, gp = 0.0;
       asm volatile("" ::: "memory");     // no LDS access may cross a step boundary (lane l reads what lane l + 1 wrote one step earlier)
       nx = ld_src<UNIFORM>(tl + t + 1);
-      if (SYM) { gx = ac[0 * AS + t]; gy = ac[1 * AS + t]; gz = ac[2 * AS + t]; }
-      double dx[KS], dy[KS], dz[KS], f[KS];
+      if (SYM) { gx = ac[0 * AS + t]; gy = ac[1 * AS + t]; gz = ac[2 * AS + t]; if (POT) gp = ac[3 * AS + t]; }
+      double dx[KS], dy[KS], dz[KS], f[KS], pr[KS];
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
         dx[k] = s.x - px[k]; dy[k] = s.y - py[k]; dz[k] = s.z - pz[k];
@@ -112,9 +121,11 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
         const double u = yv * yv;
         const double q = fma(-r2, u, 5.0 / 3.0);
         f[k] = (u * yv) * q;                         // (2/3) r^-3
-        if (GUARD) f[k] = r2 > e2 ? f[k] : 0.0;      // coincident pair at eps = 0: nothing
+        if (POT) pr[k] = yv * fma(-r2, u, 3.0);      // 2 r^-1
+        if (GUARD) { const bool apart = r2 > e2; f[k] = apart ? f[k] : 0.0; if (POT) pr[k] = apart ? pr[k] : 0.0; }   // coincident pair at eps = 0: nothing
         const double fi = UNIFORM ? f[k] : f[k] * s.w;
         fx[k] = fma(fi, dx[k], fx[k]); fy[k] = fma(fi, dy[k], fy[k]); fz[k] = fma(fi, dz[k], fz[k]);
+        if (POT) fp[k] = UNIFORM ? fp[k] + pr[k] : fma(pr[k], s.w, fp[k]);
       }
       if (SYM) {
         __builtin_amdgcn_sched_barrier(0);           // the source-side chains (which wait for the accumulator reads) stay behind the sink-side work
@@ -122,8 +133,9 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
         for (int k = 0; k < KS; ++k) {
           const double fj = UNIFORM ? f[k] : f[k] * pm[k];
           gx = fma(-fj, dx[k], gx); gy = fma(-fj, dy[k], gy); gz = fma(-fj, dz[k], gz);
+          if (POT) gp = UNIFORM ? gp + pr[k] : fma(pr[k], pm[k], gp);
         }
-        ac[0 * AS + t] = gx; ac[1 * AS + t] = gy; ac[2 * AS + t] = gz;
+        ac[0 * AS + t] = gx; ac[1 * AS + t] = gy; ac[2 * AS + t] = gz; if (POT) ac[3 * AS + t] = gp;
       }
     };
     d4 sa = ld_src<UNIFORM>(tl), sb;
@@ -132,15 +144,15 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
 
   for (int T = 0; T < ntiles; ++T) {
     const int o = o_lo + T / QT, q = T % QT;
-    const bool sym = o >= 1 && o <= H;
+    const bool sym = cross || (o >= 1 && o <= H);
     if (T + 1 < ntiles) fetch(T + 1);
     if (sym) walk(std::true_type{}); else walk(std::false_type{});
     __syncthreads();
     if (sym) {
       const int c = set_of(o);
-      double* sl = slab + (size_t)(o - max(o_begin, 1)) * 3 * n_pad + (size_t)c * SET + (size_t)q * TJ;
+      double* sl = slab + (size_t)(cross ? (int)blockIdx.x : o - max(o_begin, 1)) * NC * n_pad_src + (size_t)c * SET + (size_t)q * TJ;
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc)
+      for (int cc = 0; cc < NC; ++cc)
         for (int e = tid; e < TJ; e += BLOCK) {
           double v = 0.0;
 #pragma unroll
@@ -149,18 +161,18 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
 #pragma unroll
             for (int w2 = 0; w2 < WAVES; ++w2) { v += acc[w2][cc][TJ + e]; acc[w2][cc][TJ + e] = 0.0; }
           }
-          sl[(size_t)cc * n_pad + e] = v;
+          sl[(size_t)cc * n_pad_src + e] = v;
         }
     }
     if (T + 1 < ntiles) commit();
     __syncthreads();
   }
 
-  double* pp = part + (size_t)blockIdx.y * 3 * n_pad;
+  double* pp = part + (size_t)blockIdx.y * NC * n_pad;
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
     const int i = i0 + k * BLOCK;
-    if (i < n) { pp[i] = fx[k]; pp[n_pad + i] = fy[k]; pp[2 * n_pad + i] = fz[k]; }
+    if (i < n) { pp[i] = fx[k]; pp[n_pad + i] = fy[k]; pp[2 * n_pad + i] = fz[k]; if (POT) pp[3 * n_pad + i] = fp[k]; }
   }
 }
 
@@ -168,23 +180,28 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
 __global__ void __launch_bounds__(256)
 accel_sym_reduce_f64_kernel(const double* __restrict__ part, int ngroups, const double* __restrict__ slab, int nslots, int n, size_t n_pad,
                             double G, const double* __restrict__ m0, double* __restrict__ tot, int first, int last,
-                            double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+                            double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az, int accumulate, double* __restrict__ phi,
+                            int i_begin) {
+  const int nc = phi ? 4 : 3;
+  const int i = i_begin + blockIdx.x * blockDim.x + threadIdx.x;      // particles [i_begin, n)
   if (i >= n) return;
-  double sx = 0.0, sy = 0.0, sz = 0.0;
+  double sx = 0.0, sy = 0.0, sz = 0.0, sp = 0.0;
   for (int g = 0; g < ngroups; ++g) {
-    const double* p = part + (size_t)g * 3 * n_pad;
+    const double* p = part + (size_t)g * nc * n_pad;
     sx += p[i]; sy += p[n_pad + i]; sz += p[2 * n_pad + i];
+    if (phi) sp += p[3 * n_pad + i];
   }
 #pragma unroll 8
   for (int s = 0; s < nslots; ++s) {
-    const double* p = slab + (size_t)s * 3 * n_pad;
+    const double* p = slab + (size_t)s * nc * n_pad;
     sx += p[i]; sy += p[n_pad + i]; sz += p[2 * n_pad + i];
+    if (phi) sp += p[3 * n_pad + i];
   }
   if (tot) {
-    if (!first) { sx += tot[i]; sy += tot[(size_t)n + i]; sz += tot[2 * (size_t)n + i]; }
-    if (!last) { tot[i] = sx; tot[(size_t)n + i] = sy; tot[2 * (size_t)n + i] = sz; return; }
+    if (!first) { sx += tot[i]; sy += tot[(size_t)n + i]; sz += tot[2 * (size_t)n + i]; if (phi) sp += tot[3 * (size_t)n + i]; }
+    if (!last) { tot[i] = sx; tot[(size_t)n + i] = sy; tot[2 * (size_t)n + i] = sz; if (phi) tot[3 * (size_t)n + i] = sp; return; }
   }
+  if (phi) { const double ph = P_SCALE * (m0 ? m0[0] * sp : sp); phi[i] = accumulate ? phi[i] + ph : ph; }   // per unit G, self term included
   const double g = F_SCALE * (m0 ? G * m0[0] : G);
   double ox = g * sx, oy = g * sy, oz = g * sz;
   if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
@@ -196,15 +213,15 @@ long long env_ll(const char* name, long long dflt) {
   return v && *v ? atoll(v) : dflt;
 }
 
-template <int KS>
+template <int KS, bool POT>
 int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const double* m, int64_t n,
-            double eps2, double G, double* ax, double* ay, double* az, int flags, long long budget, long long env_groups) {
-  constexpr int TJ = 256, SET = BLOCK * KS;
+            double eps2, double G, double* ax, double* ay, double* az, int flags, long long budget, long long env_groups, double* phi) {
+  constexpr int TJ = 256, SET = BLOCK * KS, NC = POT ? 4 : 3;
   const int nsets = (int)((n + SET - 1) / SET);
   const size_t n_pad = (size_t)nsets * SET;
   const int H = (nsets - 1) / 2;
   const int n_o = H + 1 + (nsets % 2 == 0 ? 1 : 0);
-  const size_t slot_bytes = 3 * n_pad * sizeof(double);
+  const size_t slot_bytes = NC * n_pad * sizeof(double);
   int slots_per_pass = (int)std::max<long long>(1, budget / (long long)slot_bytes);
   if (slots_per_pass > H) slots_per_pass = H > 0 ? H : 1;
   const int npass = H > 0 ? (H + slots_per_pass - 1) / slots_per_pass : 1;
@@ -213,9 +230,9 @@ int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const 
   if (groups_total > n_o) groups_total = n_o;
   const int opg = (n_o + groups_total - 1) / groups_total;
   const int max_groups_pass = (slots_per_pass + 2 + opg - 1) / opg + 1;
-  const size_t part_bytes = (size_t)max_groups_pass * 3 * n_pad * sizeof(double);
+  const size_t part_bytes = (size_t)max_groups_pass * NC * n_pad * sizeof(double);
   const size_t slab_bytes = (size_t)slots_per_pass * slot_bytes;
-  const size_t tot_bytes = npass > 1 ? 3 * (size_t)n * sizeof(double) : 0;
+  const size_t tot_bytes = npass > 1 ? NC * (size_t)n * sizeof(double) : 0;
   int rc = nb_ensure_work(c, part_bytes + slab_bytes + tot_bytes);
   if (rc) return rc;
   double* part = reinterpret_cast<double*>(c->work);
@@ -232,15 +249,59 @@ int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const 
     const int nslots = std::max(0, s_end - s_begin);
     if (ngroups > max_groups_pass) return nb_fail(c, NB_ERR_ARG, "accel_sym_f64: internal group count");
     dim3 grid(nsets, ngroups);
-#define NB_SYM_GO(GD, UF) accel_sym_f64_kernel<KS, TJ, GD, UF><<<grid, BLOCK, 0, c->stream>>>( \
-    x, y, z, m, (int)n, nsets, H, o_begin, o_end, opg, eps2, part, slab, n_pad)
+#define NB_SYM_GO(GD, UF) accel_sym_f64_kernel<KS, TJ, GD, UF, POT><<<grid, BLOCK, 0, c->stream>>>( \
+    x, y, z, m, (int)n, nsets, H, o_begin, o_end, opg, eps2, part, slab, n_pad, x, y, z, m, (int)n, nsets, n_pad, 0, 0)
     if (guard) { if (uniform) NB_SYM_GO(true, true); else NB_SYM_GO(true, false); }
     else       { if (uniform) NB_SYM_GO(false, true); else NB_SYM_GO(false, false); }
 #undef NB_SYM_GO
     NB_HIP(c, hipGetLastError());
     accel_sym_reduce_f64_kernel<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(part, ngroups, slab, nslots, (int)n, n_pad, G,
                                                                                  uniform ? m : nullptr, tot, ps == 0, ps == npass - 1,
-                                                                                 ax, ay, az, accumulate);
+                                                                                 ax, ay, az, accumulate, phi, 0);
+    NB_HIP(c, hipGetLastError());
+  }
+  return NB_OK;
+}
+
+// Block A against a different block B, every A-B pair once (see accel_sym_f32.hip: run_cross)
+template <int KS, bool POT>
+int run_cross(nb_ctx* c, const double* xa, const double* ya, const double* za, const double* ma, int64_t na,
+              const double* xb, const double* yb, const double* zb, const double* mb, int64_t nb,
+              double eps2, double G, double* aax, double* aay, double* aaz, double* bax, double* bay, double* baz,
+              double* phi_a, double* phi_b, int flags, long long budget) {
+  constexpr int TJ = 256, SET = BLOCK * KS, NC = POT ? 4 : 3;
+  const int nsa = (int)((na + SET - 1) / SET), nsb = (int)((nb + SET - 1) / SET);
+  const size_t npa = (size_t)nsa * SET, npb = (size_t)nsb * SET;
+  const size_t slot_bytes = NC * npb * sizeof(double);
+  int sets_per_pass = (int)std::max<long long>(1, budget / (long long)slot_bytes);
+  if (sets_per_pass > nsa) sets_per_pass = nsa;
+  int groups = (4096 + sets_per_pass - 1) / sets_per_pass;
+  if (groups > nsb) groups = nsb;
+  if (groups < 1) groups = 1;
+  const int opg = (nsb + groups - 1) / groups;
+  groups = (nsb + opg - 1) / opg;
+  const size_t part_bytes = (size_t)groups * NC * npa * sizeof(double);
+  int rc = nb_ensure_work(c, part_bytes + (size_t)sets_per_pass * slot_bytes);
+  if (rc) return rc;
+  double* part = reinterpret_cast<double*>(c->work);
+  double* slab = reinterpret_cast<double*>(reinterpret_cast<char*>(c->work) + part_bytes);
+  const bool uniform = (flags & NB_UNIFORM_MASS) != 0;
+  const bool guard = !(eps2 > 0.0);
+  for (int b0 = 0; b0 < nsa; b0 += sets_per_pass) {
+    const int nb_sets = std::min(sets_per_pass, nsa - b0);
+    dim3 grid(nb_sets, groups);
+#define NB_SYM_GO(GD, UF) accel_sym_f64_kernel<KS, TJ, GD, UF, POT><<<grid, BLOCK, 0, c->stream>>>( \
+    xa, ya, za, ma, (int)na, nsa, 0, 0, nsb, opg, eps2, part, slab, npa, xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0)
+    if (guard) { if (uniform) NB_SYM_GO(true, true); else NB_SYM_GO(true, false); }
+    else       { if (uniform) NB_SYM_GO(false, true); else NB_SYM_GO(false, false); }
+#undef NB_SYM_GO
+    NB_HIP(c, hipGetLastError());
+    const int i_begin = b0 * SET, i_end = (int)std::min<int64_t>(na, (int64_t)(b0 + nb_sets) * SET);
+    accel_sym_reduce_f64_kernel<<<(i_end - i_begin + 255) / 256, 256, 0, c->stream>>>(part, groups, nullptr, 0, i_end, npa, G, uniform ? ma : nullptr,
+                                                                                       nullptr, 1, 1, aax, aay, aaz, flags & NB_ACCUMULATE, phi_a, i_begin);
+    NB_HIP(c, hipGetLastError());
+    accel_sym_reduce_f64_kernel<<<(int)((nb + 255) / 256), 256, 0, c->stream>>>(nullptr, 0, slab, nb_sets, (int)nb, npb, G, uniform ? ma : nullptr,
+                                                                                 nullptr, 1, 1, bax, bay, baz, b0 > 0, phi_b, 0);
     NB_HIP(c, hipGetLastError());
   }
   return NB_OK;
@@ -250,11 +311,14 @@ int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const 
 
 // Self-interaction launch (sinks == sources); *taken = 0: not applicable (small n, switched off with NB_F64_SYM=0) — use the one-sided kernel
 int nb_launch_accel_sym_f64(nb_ctx* c, const double* x, const double* y, const double* z, const double* m, int64_t n,
-                            double eps2, double G, double* ax, double* ay, double* az, int flags, int* taken) {
+                            double eps2, double G, double* ax, double* ay, double* az, int flags, double* phi, int* taken) {
   *taken = 0;
-  static const long long mode = env_ll("NB_F64_SYM", 1), min_n = env_ll("NB_F64_SYM_MIN_N", 16384),
-                         budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_groups = env_ll("NB_F64_SYM_GROUPS", 0),
+  c->last_accel_sym = false;
+  static const long long env_mode = env_ll("NB_F64_SYM", 1), env_min_n = env_ll("NB_F64_SYM_MIN_N", 16384),
+                         env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_groups = env_ll("NB_F64_SYM_GROUPS", 0),
                          env_ks = env_ll("NB_F64_SYM_KS", 0);
+  const long long mode = c->sym_enable >= 0 ? c->sym_enable : env_mode, min_n = c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
+                  budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
   if (!mode || n < min_n || n >= (1ll << 31) || n <= BLOCK * 2) return NB_OK;
   // sinks per lane: 8 for large n (N = 2^19, equal masses: 80.4 ms against 85.1 with 4 and 96.9 with 2; the one-sided kernel: 126.9), smaller
   // sets for smaller n so that the launch still has a few thousand (set, offset) tiles
@@ -263,10 +327,38 @@ int nb_launch_accel_sym_f64(nb_ctx* c, const double* x, const double* y, const d
   if (tiles(8) < 2500) ks = 4;
   if (ks == 4 && tiles(4) < 2500) ks = 2;
   if (env_ks == 2 || env_ks == 4 || env_ks == 8) ks = (int)env_ks;
-  const int rc = ks == 8 ? run_sym<8>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups)
-               : ks == 4 ? run_sym<4>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups)
-                         : run_sym<2>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups);
+#define NB_RUN(K, PT) run_sym<K, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups, phi)
+  const int rc = phi ? (ks == 8 ? NB_RUN(8, true) : ks == 4 ? NB_RUN(4, true) : NB_RUN(2, true))
+                     : (ks == 8 ? NB_RUN(8, false) : ks == 4 ? NB_RUN(4, false) : NB_RUN(2, false));
+#undef NB_RUN
   if (rc) return rc;
   *taken = 1;
+  c->last_accel_sym = true;
+  return NB_OK;
+}
+
+// Two different blocks, every A-B pair once; *taken = 0: not applicable — the caller runs the one-sided kernel in both directions
+int nb_launch_accel_cross_f64(nb_ctx* c, const double* xa, const double* ya, const double* za, const double* ma, int64_t na,
+                              const double* xb, const double* yb, const double* zb, const double* mb, int64_t nb,
+                              double eps2, double G, double* aax, double* aay, double* aaz, double* bax, double* bay, double* baz,
+                              double* phi_a, double* phi_b, int flags, int* taken) {
+  *taken = 0;
+  static const long long env_mode = env_ll("NB_F64_SYM", 1), env_min_n = env_ll("NB_F64_SYM_MIN_N", 16384), env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30);
+  const long long mode = c->sym_enable >= 0 ? c->sym_enable : env_mode, min_n = c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
+                  budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
+  const int64_t nmin = std::min(na, nb);
+  if (!mode || nmin * 2 < min_n || na >= (1ll << 31) || nb >= (1ll << 31) || nmin < 1) return NB_OK;
+  auto tiles = [&](int ks) { const long long sa = (na + BLOCK * ks - 1) / (BLOCK * ks), sb = (nb + BLOCK * ks - 1) / (BLOCK * ks); return sa * sb; };
+  const bool pot = phi_a != nullptr;
+  int ks = 8;
+  if (tiles(8) < 2500) ks = 4;
+  if (ks == 4 && tiles(4) < 2500) ks = 2;
+#define NB_RUN(K, PT) run_cross<K, PT>(c, xa, ya, za, ma, na, xb, yb, zb, mb, nb, eps2, G, aax, aay, aaz, bax, bay, baz, phi_a, phi_b, flags, budget)
+  const int rc = pot ? (ks == 8 ? NB_RUN(8, true) : ks == 4 ? NB_RUN(4, true) : NB_RUN(2, true))
+                     : (ks == 8 ? NB_RUN(8, false) : ks == 4 ? NB_RUN(4, false) : NB_RUN(2, false));
+#undef NB_RUN
+  if (rc) return rc;
+  *taken = 1;
+  c->last_accel_sym = true;
   return NB_OK;
 }

@@ -555,6 +555,22 @@ int nb_rung_step(nb_ctx* c, int levels, const double* kc, const double* dc, doub
 
 int nb_last_run_used_graph(const nb_ctx* c) { return c ? (c->graph_replayed ? 1 : 0) : NB_ERR_ARG; }
 
+int nb_set_option(nb_ctx* c, int option, int64_t value) {
+  if (!c) return NB_ERR_ARG;
+  const long long v = value < 0 ? -1 : (long long)value;
+  switch (option) {
+    case NB_OPT_PAIR_SYMMETRY: c->sym_enable = v; break;
+    case NB_OPT_SYM_MIN_N: c->sym_min_n = v; break;
+    case NB_OPT_SYM_SLAB_BYTES: c->sym_slab_bytes = v; break;
+    default: return nb_fail(c, NB_ERR_ARG, "nb_set_option: unknown option");
+  }
+  c->acc_valid = false;                               // the cached accelerations came from the other kernel's summation order
+  if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }   // a captured step holds the old choice
+  return NB_OK;
+}
+
+int nb_last_accel_symmetric(const nb_ctx* c) { return c ? (c->last_accel_sym ? 1 : 0) : NB_ERR_ARG; }
+
 int nb_energy(nb_ctx* c, double eps, double G, double* kinetic, double* potential) {
   if (!c) return NB_ERR_ARG;
   if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_energy: call nb_set_state first");
@@ -665,6 +681,52 @@ int nb_accel_pot_dev(nb_ctx* c, int dtype, const void* xi, const void* yi, const
                                (const double*)ys, (const double*)zs, (const double*)ms, n_src, eps * eps, G,
                                (double*)ax, (double*)ay, (double*)az, flags, phi);
   return nb_fail(c, NB_ERR_ARG, "nb_accel_pot_dev: unknown dtype");
+}
+
+int nb_accel_pair_dev(nb_ctx* c, int dtype, const void* xa, const void* ya, const void* za, const void* ma, int64_t na,
+                      const void* xb, const void* yb, const void* zb, const void* mb, int64_t nb, double eps, double G,
+                      void* aax, void* aay, void* aaz, void* bax, void* bay, void* baz, double* phi_a, double* phi_b, int flags) {
+  if (!c) return NB_ERR_ARG;
+  NB_SINGLE_ONLY(c, "nb_accel_pair_dev");
+  if (na < 0 || nb < 0) return nb_fail(c, NB_ERR_ARG, "nb_accel_pair_dev: negative count");
+  if (na > 0 && (!xa || !ya || !za || !ma || !aax || !aay || !aaz)) return nb_fail(c, NB_ERR_ARG, "nb_accel_pair_dev: NULL array of block A");
+  if (nb > 0 && (!xb || !yb || !zb || !mb || !bax || !bay || !baz)) return nb_fail(c, NB_ERR_ARG, "nb_accel_pair_dev: NULL array of block B");
+  if ((phi_a == nullptr) != (phi_b == nullptr)) return nb_fail(c, NB_ERR_ARG, "nb_accel_pair_dev: phi_a and phi_b go together");
+  if (xa == xb || aax == bax) return nb_fail(c, NB_ERR_ARG, "nb_accel_pair_dev: A and B must be different blocks (a block on itself: nb_accel_dev)");
+  if (!(eps >= 0.0)) return nb_fail(c, NB_ERR_ARG, "nb_accel_pair_dev: eps must be >= 0");
+  if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_accel_pair_dev: unknown dtype");
+  int rc = use_device(c); if (rc) return rc;
+  c->last_accel_sym = false;
+  const int fl_b = flags & ~NB_ACCUMULATE;                    // B's arrays are overwritten
+  if (na == 0 || nb == 0) {                                   // nothing to exchange: B's output is zero, A's untouched
+    if (nb > 0) {
+      const size_t bytes = (size_t)nb * esize(dtype);
+      NB_HIP(c, hipMemsetAsync(bax, 0, bytes, c->stream)); NB_HIP(c, hipMemsetAsync(bay, 0, bytes, c->stream)); NB_HIP(c, hipMemsetAsync(baz, 0, bytes, c->stream));
+      if (phi_b) NB_HIP(c, hipMemsetAsync(phi_b, 0, (size_t)nb * sizeof(double), c->stream));
+    }
+    return NB_OK;
+  }
+  int taken = 0;
+  if (dtype == NB_F32) {
+    rc = nb_launch_accel_cross_f32(c, (const float*)xa, (const float*)ya, (const float*)za, (const float*)ma, na, (const float*)xb, (const float*)yb,
+                                   (const float*)zb, (const float*)mb, nb, (float)(eps * eps), (float)G, (float*)aax, (float*)aay, (float*)aaz,
+                                   (float*)bax, (float*)bay, (float*)baz, phi_a, phi_b, flags, &taken);
+    if (rc || taken) return rc;
+    rc = nb_launch_accel_f32(c, (const float*)xa, (const float*)ya, (const float*)za, na, (const float*)xb, (const float*)yb, (const float*)zb,
+                             (const float*)mb, nb, (float)(eps * eps), (float)G, (float*)aax, (float*)aay, (float*)aaz, flags, phi_a);
+    if (rc) return rc;
+    return nb_launch_accel_f32(c, (const float*)xb, (const float*)yb, (const float*)zb, nb, (const float*)xa, (const float*)ya, (const float*)za,
+                               (const float*)ma, na, (float)(eps * eps), (float)G, (float*)bax, (float*)bay, (float*)baz, fl_b, phi_b);
+  }
+  rc = nb_launch_accel_cross_f64(c, (const double*)xa, (const double*)ya, (const double*)za, (const double*)ma, na, (const double*)xb, (const double*)yb,
+                                 (const double*)zb, (const double*)mb, nb, eps * eps, G, (double*)aax, (double*)aay, (double*)aaz,
+                                 (double*)bax, (double*)bay, (double*)baz, phi_a, phi_b, flags, &taken);
+  if (rc || taken) return rc;
+  rc = nb_launch_accel_f64(c, (const double*)xa, (const double*)ya, (const double*)za, na, (const double*)xb, (const double*)yb, (const double*)zb,
+                           (const double*)mb, nb, eps * eps, G, (double*)aax, (double*)aay, (double*)aaz, flags, phi_a);
+  if (rc) return rc;
+  return nb_launch_accel_f64(c, (const double*)xb, (const double*)yb, (const double*)zb, nb, (const double*)xa, (const double*)ya, (const double*)za,
+                             (const double*)ma, na, eps * eps, G, (double*)bax, (double*)bay, (double*)baz, fl_b, phi_b);
 }
 
 int nb_pot_energy_dev(nb_ctx* c, int dtype, const double* phi, const void* m, int64_t n, double eps, int uniform, double* w_out) {

@@ -42,6 +42,9 @@ struct nb_ctx {
   int sr_min_rung = 0;
   bool lr_valid = false;             // acc_lr / the state's acc hold a_lr / a_sr of the current positions, computed with (lr_eps, lr_G)
   double lr_eps = -1.0, lr_G = 0.0;
+  // pair-symmetric self-interaction kernels (accel_sym_*.hip): per-context options (-1 = process default) and what the last launch took
+  long long sym_enable = -1, sym_min_n = -1, sym_slab_bytes = -1;
+  bool last_accel_sym = false;
   bool graph_replayed = false;   // the last nb_kdk_run replayed a captured step (diagnostic: nb_last_run_used_graph)
   // force solver used by nb_accel / nb_step: direct summation (default) or Barnes-Hut tree (fp32 only)
   int solver = 0;
@@ -74,9 +77,18 @@ int nb_launch_accel_f32(nb_ctx* c, const float* xi, const float* yi, const float
                         float eps2, float G, float* ax, float* ay, float* az, int flags, double* phi = nullptr);
 // pair-symmetric self-interaction (sinks == sources, each unordered pair evaluated once); *taken = 0: not applicable, use the one-sided kernel
 int nb_launch_accel_sym_f32(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
-                            float eps2, float G, float* ax, float* ay, float* az, int flags, int* taken);
+                            float eps2, float G, float* ax, float* ay, float* az, int flags, double* phi, int* taken);
 int nb_launch_accel_sym_f64(nb_ctx* c, const double* x, const double* y, const double* z, const double* m, int64_t n,
-                            double eps2, double G, double* ax, double* ay, double* az, int flags, int* taken);
+                            double eps2, double G, double* ax, double* ay, double* az, int flags, double* phi, int* taken);
+// two DIFFERENT blocks, every A-B pair evaluated once: A's accelerations (+)= the force of B, B's (bax..) = the force of A; *taken = 0: not applicable
+int nb_launch_accel_cross_f32(nb_ctx* c, const float* xa, const float* ya, const float* za, const float* ma, int64_t na,
+                              const float* xb, const float* yb, const float* zb, const float* mb, int64_t nb,
+                              float eps2, float G, float* aax, float* aay, float* aaz, float* bax, float* bay, float* baz,
+                              double* phi_a, double* phi_b, int flags, int* taken);
+int nb_launch_accel_cross_f64(nb_ctx* c, const double* xa, const double* ya, const double* za, const double* ma, int64_t na,
+                              const double* xb, const double* yb, const double* zb, const double* mb, int64_t nb,
+                              double eps2, double G, double* aax, double* aay, double* aaz, double* bax, double* bay, double* baz,
+                              double* phi_a, double* phi_b, int flags, int* taken);
 int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const double* zi, int64_t n_snk,
                         const double* xs, const double* ys, const double* zs, const double* ms, int64_t n_src,
                         double eps2, double G, double* ax, double* ay, double* az, int flags, double* phi = nullptr);

@@ -58,6 +58,14 @@ class HipKernels:
         except Exception:
             pass
 
+    def set_option(self, name: str, value: int) -> None:
+        """nb_set_option on the launch context: 'pair_symmetry' 0/1, 'sym_min_n', 'sym_slab_bytes' (value < 0: default)."""
+        _lib.check(self._ctx, self._lib.nb_set_option(self._ctx, {"pair_symmetry": 1, "sym_min_n": 2, "sym_slab_bytes": 3}[name], int(value)),
+                   "nb_set_option")
+
+    def last_accel_symmetric(self) -> bool:
+        return bool(self._lib.nb_last_accel_symmetric(self._ctx))
+
     def _bind(self):
         cur = self._torch.cuda.current_stream()
         s = cur.cuda_stream
@@ -104,6 +112,21 @@ class HipKernels:
                                         ax, ay, az, C.c_void_p(phi.data_ptr()),
                                         (_lib.NB_ACCUMULATE if accumulate else 0) | (_lib.NB_UNIFORM_MASS if uniform_mass else 0))
         _lib.check(self._ctx, rc, "nb_accel_pot_dev")
+
+    def accel_pair(self, blk_a, n_a, blk_b, n_b, eps, G, acc_a, acc_b, accumulate, uniform_mass=False, phi_a=None, phi_b=None):
+        """Two different blocks, every A-B pair once (nb_accel_pair_dev): acc_a (+)= force of B on A, acc_b = force of A on B (overwritten);
+        phi_a / phi_b (float64, both or neither): the fused potential, phi_a accumulating like acc_a."""
+        self._bind()
+        xa, ya, za, ma = self._rows(blk_a, 4)
+        xb, yb, zb, mb = self._rows(blk_b, 4)
+        aax, aay, aaz = self._rows(acc_a, 3)
+        bax, bay, baz = self._rows(acc_b, 3)
+        pa = C.c_void_p(phi_a.data_ptr()) if phi_a is not None else None
+        pb = C.c_void_p(phi_b.data_ptr()) if phi_b is not None else None
+        rc = self._lib.nb_accel_pair_dev(self._ctx, self._code(blk_a), xa, ya, za, ma, n_a, xb, yb, zb, mb, n_b, eps, G, aax, aay, aaz,
+                                         bax, bay, baz, pa, pb,
+                                         (_lib.NB_ACCUMULATE if accumulate else 0) | (_lib.NB_UNIFORM_MASS if uniform_mass else 0))
+        _lib.check(self._ctx, rc, "nb_accel_pair_dev")
 
     def pot_energy(self, phi, mass_row, n, eps, out, uniform_mass=False):
         """out[0] = sum_i m_i (phi_i - self term) for the phi of accel_pot() accumulated over all source chunks."""
@@ -203,8 +226,14 @@ class HopProbe:
 class ShardedEngine:
     """Sink-decomposed engine of one rank. All ranks must make the same sequence of calls."""
 
-    def __init__(self, n_total: int, dtype=np.float32, device=None, group=None, kernels=None, mode: str = "ring", virtual_world: int = 0):
-        """virtual_world = P > 1 (rehearsal on ONE GPU with the real transport): the process group has a single rank, which plays rank 0 of a
+    def __init__(self, n_total: int, dtype=np.float32, device=None, group=None, kernels=None, mode: str = "ring", virtual_world: int = 0,
+                 pairwise=None):
+        """pairwise (default: on for more than one rank when the kernel backend offers accel_pair): every pair of chunks is worked on by ONE of
+        its two owners — rank r takes the chunks of ranks r-1 .. r-(P-1)//2 two-sidedly (nb_accel_pair_dev: each A-B pair evaluated once) and
+        sends the other owner its partial sums, point to point; for an even P the chunk half-way round is met from both sides one-sidedly.
+        The position ring then runs P//2 hops instead of P-1 and the pair work per rank halves (DESIGN.md §5.3). pairwise=False: every rank
+        sums all P chunks one-sidedly for its own sinks (no accelerations travel).
+        virtual_world = P > 1 (rehearsal on ONE GPU with the real transport): the process group has a single rank, which plays rank 0 of a
         P-rank ring — it owns the first of P sink ranges, holds the other ranks' source blocks locally, and at every hop sends the block its
         predecessor would have sent TO ITSELF through the communicator (RCCL supports a send/receive pair on one rank). Everything the
         RCCL path relies on is then exercised for real — batch_isend_irecv posted before the kernel, the communicator stream's ordering against the
@@ -247,10 +276,20 @@ class ShardedEngine:
         if virtual_world and virtual_world > 1:
             self.virtual = z(self.world, 4, self.n_max)      # the source blocks of the other (virtual) ranks
         self.gathered = z(self.world, 4, self.n_max) if (self.world > 1 and mode == "allgather") else None
+        # pair-symmetric schedule: partial sums of the visiting chunk (sent back to its owner; two buffers in flight) and the partials of the
+        # own chunk returned by the (P-1)//2 ranks that were handed it
+        if pairwise is None:
+            pairwise = self.world > 1 and hasattr(kernels, "accel_pair") and self.virtual is None
+        self.pairwise = bool(pairwise) and self.world > 1
+        self.H = (self.world - 1) // 2 if self.pairwise else 0
+        self.out = [z(3, self.n_max), z(3, self.n_max)] if self.H > 0 else []
+        self.back = [z(3, self.n_max) for _ in range(self.H)]
+        self.out_phi, self.back_phi = [], []
         self.scal = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.phi = None                # per-sink potential of the fused force+potential kernels (step_with_energy)
         self._acc_key = None
         self.uniform_mass = False
+        self.own_chunk_symmetric = False   # the last accel() ran the pair-symmetric kernel on this rank's own chunk (HIP backend only)
         self.kernel_timer = None   # optional object with begin()/end(interactions): brackets every accel launch
         self.hop_probe = None      # optional HopProbe: per-hop exchange time next to the kernel it overlaps
 
@@ -347,11 +386,115 @@ class ShardedEngine:
                     q.wait()
                 cur = recv_buf
 
+    def _accel_pairwise(self, eps: float, G: float, with_potential: bool) -> None:
+        """The pair-symmetric schedule (see __init__): own chunk (symmetric inside the kernel), then the chunks of ranks r-1 .. r-H
+        two-sidedly with the partial sums sent back to their owners, then — P even — the chunk half-way round one-sidedly."""
+        t, dist = self._torch, self._dist
+        P, r, H = self.world, self.rank, self.H
+        half = P % 2 == 0
+        hops = H + (1 if half else 0)                  # chunks that have to arrive
+        tm = self.kernel_timer
+        unordered = self.device.type == "cuda" and dist.get_backend(self.group) != "nccl"
+        fence = (lambda: t.cuda.current_stream(self.device).synchronize()) if unordered else (lambda: None)
+        glob = (lambda k: dist.get_global_rank(self.group, k)) if self.group is not None else (lambda k: k)
+        if with_potential and not self.out_phi:
+            zf = lambda: t.zeros(self.n_max, dtype=t.float64, device=self.device)
+            self.out_phi, self.back_phi = [zf(), zf()], [zf() for _ in range(H)]
+
+        gather = None
+        if self.mode == "allgather":
+            fence()
+            gather = dist.all_gather_into_tensor(self.gathered.view(-1), self.pm.view(-1), group=self.group, async_op=True)
+        if self.virtual is not None:
+            nxt_rank = prv_rank = glob(dist.get_rank(self.group))
+        else:
+            nxt_rank, prv_rank = glob((r + 1) % P), glob((r - 1) % P)
+
+        def kernel(h, cur):
+            owner = (r - h) % P
+            if tm is not None:
+                tm.begin()
+            if h == 0 or h > H:                          # own chunk / the chunk half-way round: this rank's sinks only
+                if with_potential:
+                    self.k.accel_pot(self.pm, self.n_loc, cur, self.counts[owner], eps, G, self.acc, self.phi, h > 0, self.uniform_mass)
+                else:
+                    self.k.accel(self.pm, self.n_loc, cur, self.counts[owner], eps, G, self.acc, h > 0, self.uniform_mass)
+                if h == 0 and hasattr(self.k, "last_accel_symmetric"):
+                    self.own_chunk_symmetric = self.k.last_accel_symmetric()
+            else:                                        # every pair of (own chunk, visiting chunk) once; the visitor's sums go home
+                self.k.accel_pair(self.pm, self.n_loc, cur, self.counts[owner], eps, G, self.acc, self.out[h & 1], True, self.uniform_mass,
+                                  self.phi if with_potential else None, self.out_phi[h & 1] if with_potential else None)
+            if tm is not None:                           # interactions DELIVERED by the launch: both directions of a two-sided hop
+                tm.end(float(self.n_loc) * float(self.counts[owner]) * (2.0 if 0 < h <= H else 1.0))
+
+        cur = self.pm
+        back_reqs = [None] * (H + 1)
+        for h in range(hops + 1):
+            reqs = None
+            if h < hops and self.mode == "ring":
+                fence()
+                if self.hop_probe is not None and self.hop_probe.enabled:
+                    self.hop_probe.posting()
+                recv_buf = self.ring[h & 1]
+                send_buf = cur if self.virtual is None else self.virtual[(r - h - 1) % P]
+                reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, send_buf, nxt_rank, self.group),
+                                               dist.P2POp(dist.irecv, recv_buf, prv_rank, self.group)])   # posted before the kernel: runs beside it
+            if 2 <= h <= H and back_reqs[h - 2] is not None:  # the partial buffer of hop h - 2 is about to be overwritten: its send must be through
+                for q in back_reqs[h - 2]:
+                    q.wait()
+                back_reqs[h - 2] = None
+            probe = self.hop_probe if (reqs is not None and self.hop_probe is not None and self.hop_probe.enabled) else None
+            if probe is not None:
+                probe.exchange(reqs, lambda: kernel(h, cur), host_blocking=unordered or self.device.type != "cuda")
+            else:
+                kernel(h, cur)
+            if 1 <= h <= H:                              # the visitor's partial goes to its owner; mine comes from the rank holding my chunk now
+                fence()
+                if self.virtual is None:
+                    to, frm, payload = glob((r - h) % P), glob((r + h) % P), self.out[h & 1]
+                    payload_phi = self.out_phi[h & 1] if with_potential else None
+                else:                                    # one real rank: what rank r + h would send is computed here and sent to itself
+                    to = frm = glob(dist.get_rank(self.group))
+                    o = (r + h) % P
+                    payload = t.zeros_like(self.out[0])
+                    scratch = t.zeros_like(self.out[0])
+                    payload_phi = t.zeros(self.n_max, dtype=t.float64, device=self.device) if with_potential else None
+                    self.k.accel_pair(self.virtual[o], self.counts[o], self.pm, self.n_loc, eps, G, scratch, payload, False, self.uniform_mass,
+                                      t.zeros_like(payload_phi) if with_potential else None, payload_phi)
+                    fence()
+                ops = [dist.P2POp(dist.isend, payload, to, self.group), dist.P2POp(dist.irecv, self.back[h - 1], frm, self.group)]
+                if with_potential:
+                    ops += [dist.P2POp(dist.isend, payload_phi, to, self.group), dist.P2POp(dist.irecv, self.back_phi[h - 1], frm, self.group)]
+                back_reqs[h] = dist.batch_isend_irecv(ops)
+            if probe is None and reqs is not None:
+                for q in reqs:
+                    q.wait()
+            if h < hops:
+                if self.mode == "ring":
+                    cur = recv_buf
+                else:
+                    if gather is not None:
+                        gather.wait()
+                        gather = None
+                    cur = self.gathered[(r - h - 1) % P]
+        for reqs in back_reqs:
+            if reqs is not None:
+                for q in reqs:
+                    q.wait()
+        for h in range(1, H + 1):                        # fixed order: bit-reproducible
+            self.acc[:, : self.n_loc] += self.back[h - 1][:, : self.n_loc]
+            if with_potential:
+                self.phi[: self.n_loc] += self.back_phi[h - 1][: self.n_loc]
+
     def accel(self, eps: float, G: float = 1.0, with_potential: bool = False) -> None:
         """acc <- a(x) of the owned sinks due to ALL particles; with_potential also accumulates self.phi over the chunks."""
         tm = self.kernel_timer
         if with_potential and self.phi is None:
             self.phi = self._torch.zeros(self.n_max, dtype=self._torch.float64, device=self.device)
+        if self.pairwise:
+            self._accel_pairwise(eps, G, with_potential)
+            self._acc_key = (eps, G)
+            return
 
         def one(src, owner, first):
             if tm is not None:
@@ -362,6 +505,8 @@ class ShardedEngine:
                 self.k.accel(self.pm, self.n_loc, src, self.counts[owner], eps, G, self.acc, not first, self.uniform_mass)
             if tm is not None:
                 tm.end(float(self.n_loc) * float(self.counts[owner]))
+            if first and hasattr(self.k, "last_accel_symmetric"):
+                self.own_chunk_symmetric = self.k.last_accel_symmetric()
         self._for_each_chunk(one)
         self._acc_key = (eps, G)
 

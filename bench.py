@@ -40,13 +40,15 @@ FLOP_PER_INTERACTION = 20.0        # Nyland-Harris-Prins convention, SURVEY.md Â
 PEAK_FP32_VECTOR_TFLOPS = 157.3    # MI355X_MICROARCH.md "Peak FP32 (vector)"
 PEAK_FP64_VECTOR_TFLOPS = 78.6
 PEAK_CLOCK_MHZ = 2400.0            # the clock both peaks are quoted at (256 CUs x 256 flop/clk x 2.4 GHz)
+EXECUTED_FLOP_ONE_SIDED = 19.0     # one-sided kernels, per ordered interaction: 3 sub, 3 fma, rsqrt, 3 mul, 3 fma (equal masses: 18)
+EXECUTED_FLOP_SYM = 12.0           # pair-symmetric kernels: 24 per unordered pair = 12 per delivered (ordered) interaction
 
 
 def measured_traffic():
     """HBM bytes per accel launch from the committed rocprofv3 PMC passes of THIS command (tools/profile.sh ->
-    profiles/r02_bench_n1_uniform_rocprofv3_summary.txt: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE). bench.py
+    profiles/r03_bench_n1_uniform_rocprofv3_summary.txt: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE). bench.py
     cannot run the profiler around itself, so the number is the profile's, or None if the file is absent."""
-    f = ROOT / "profiles" / "r02_bench_n1_uniform_rocprofv3_summary.txt"
+    f = ROOT / "profiles" / "r03_bench_n1_uniform_rocprofv3_summary.txt"
     try:
         rd = wr = None
         for line in f.read_text().splitlines():
@@ -353,6 +355,7 @@ def main():
         elapsed = float(t[0].item())
         clock_min = -float(t[1].item()) if clock_mhz else None
 
+    symmetric = eng.k.last_accel_symmetric() if world == 1 else eng.own_chunk_symmetric
     interactions = float(args.n) * float(args.n) * args.steps
     value = interactions / elapsed
     k_ms, k_inter, k_count = timer.summary()
@@ -383,15 +386,23 @@ def main():
             # compute stream still had to wait for (0 = hidden)
             "ring": probe.summary() if probe is not None else None,
             "roofline": {"bound": "vector_" + ("fp32" if args.dtype == "f32" else "fp64"),
-                         "kernel": "accel_%s_kernel" % args.dtype,
+                         "kernel": ("accel_sym_%s_kernel" if (symmetric and world == 1) else "accel_%s_kernel") % args.dtype,
                          "variant": "uniform_mass" if eng.uniform_mass else "general",
+                         # SURVEY.md Â§8(d): achieved = ORDERED interactions per launch x 20 flop / launch time â€” the convention the metric is quoted in
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "flop_per_interaction": FLOP_PER_INTERACTION,
+                         # the pair-symmetric kernel evaluates every UNORDERED pair once and gives both particles their term (Newton III):
+                         # N^2 ordered interactions are DELIVERED per launch, (N^2 + N * set) / 2 pair terms are EVALUATED, at 24 flop each
+                         # (3 sub, 3 fma, rsqrt, 2 mul, 6 fma) = 12 flop per delivered interaction instead of the convention's 20
+                         "pair_symmetry": bool(symmetric),
+                         "pair_symmetry_scope": (None if not symmetric else "every launch" if world == 1 else "own-chunk launch of each rank only"),
+                         "executed_flop_per_interaction": EXECUTED_FLOP_SYM if (symmetric and world == 1) else EXECUTED_FLOP_ONE_SIDED,
+                         "frac_executed_flops": achieved / peak * (EXECUTED_FLOP_SYM if (symmetric and world == 1) else EXECUTED_FLOP_ONE_SIDED) / FLOP_PER_INTERACTION,
                          "interactions_per_launch": k_inter, "avg_launch_ms": k_ms, "launches_timed": k_count,
                          # rank 0's accel launches per step, back to back: what ms_per_step would be with a free exchange and free O(N) kernels
                          "kernel_ms_per_step": k_ms * k_count / max(1, args.steps),
                          "traffic": None,
-                         "traffic_source": "NOT measured in this run: HBM bytes per launch from the rocprofv3 --pmc passes of this same command committed as profiles/r02_bench_n1_uniform_rocprofv3_summary.txt (FETCH_SIZE x2 + WRITE_SIZE; 0.4 GB = the fp64 slab of the 8-way source split); algorithmic bytes = 28*N"},
+                         "traffic_source": "NOT measured in this run: HBM bytes per launch from the rocprofv3 --pmc passes of this same command committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE: the partial-sum slabs of the pair-symmetric kernel); algorithmic bytes = 28*N"},
         }
         r = out["roofline"]
         if clock_mhz:

@@ -126,6 +126,20 @@ int nb_rung_step(nb_ctx* ctx, int levels, const double* kc, const double* dc, do
  * runtime refused). Results are bit-identical either way. */
 int nb_last_run_used_graph(const nb_ctx* ctx);
 
+/* ---- the pair-symmetric all-pairs kernels (direct solver, a particle set on itself: nb_accel / nb_step / nb_energy paths and nb_accel_dev
+ * with identical sink and source arrays) evaluate every unordered pair once and give both particles their term (csrc/accel_sym_f32.hip,
+ * accel_sym_f64.hip); results agree with the one-sided kernels to rounding (different summation order). Options of a context:
+ *   NB_OPT_PAIR_SYMMETRY : 1 = use them where they apply (default; process-wide default from NB_F32_SYM / NB_F64_SYM), 0 = one-sided kernels only
+ *   NB_OPT_SYM_MIN_N     : smallest n that takes them (default 32768 fp32 / 16384 fp64: below, the one-sided kernel is faster)
+ *   NB_OPT_SYM_SLAB_BYTES: scratch budget for the per-offset partial-sum slabs (default 4 GiB); larger problems run in several passes
+ * value < 0 restores the default. No counterpart in the reference (CONCEPT's pp solver is not in the repository). */
+#define NB_OPT_PAIR_SYMMETRY 1
+#define NB_OPT_SYM_MIN_N 2
+#define NB_OPT_SYM_SLAB_BYTES 3
+int nb_set_option(nb_ctx* ctx, int option, int64_t value);
+/* 1 if the last direct-summation force launch of this context ran the pair-symmetric kernel, 0 if the one-sided one */
+int nb_last_accel_symmetric(const nb_ctx* ctx);
+
 /* ---- measurement aid ("reported absolute and as a fraction of the vector-FP32 roofline") ----
  * Sustained shader clock of `device` over the next `window_ms` milliseconds at most (clamped to 5 s), measured by one sleeping wave on a private
  * stream that reads the shader-cycle counter and the constant-rate counter at both ends of the window — start it, run the kernels of
@@ -173,6 +187,15 @@ int nb_accel_pot_dev(nb_ctx* ctx, int dtype,
                      const void* xi, const void* yi, const void* zi, int64_t n_snk,
                      const void* xs, const void* ys, const void* zs, const void* ms, int64_t n_src,
                      double eps, double G, void* ax, void* ay, void* az, double* phi, int flags);
+/* Two DIFFERENT device blocks, every A-B pair evaluated ONCE (the pair-symmetric kernels in their two-block form): block A's accelerations
+ * aax.. (+)= the force of B on A (NB_ACCUMULATE adds, as in nb_accel_dev), block B's arrays bax.. are OVERWRITTEN with the force of A on B —
+ * the partial a rank that was handed B's positions sends back to B's owner, which adds it to its own sums (sink decomposition with half the
+ * pair work: SURVEY.md §8e). phi_a / phi_b (both or neither; fp64): the fused potential, per unit G — phi_a accumulates with
+ * NB_ACCUMULATE, phi_b is overwritten. NB_UNIFORM_MASS: all masses of A and B are equal. Falls back to two one-sided launches where the
+ * symmetric kernel does not apply (small blocks, NB_OPT_PAIR_SYMMETRY 0): the results are the same up to summation order. */
+int nb_accel_pair_dev(nb_ctx* ctx, int dtype, const void* xa, const void* ya, const void* za, const void* ma, int64_t na,
+                      const void* xb, const void* yb, const void* zb, const void* mb, int64_t nb, double eps, double G,
+                      void* aax, void* aay, void* aaz, void* bax, void* bay, void* baz, double* phi_a, double* phi_b, int flags);
 /* w_out[0] = sum_{i<n} m_i (phi_i - self_i) (device double), phi from nb_accel_pot_dev over ALL sources; self_i is the i = j term
  * exactly as the force kernel added it (0 when eps = 0). `uniform` = the NB_UNIFORM_MASS flag the phi was computed with. The
  * caller sums over ranks and applies -G/2. */

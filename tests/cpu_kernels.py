@@ -27,6 +27,15 @@ class OracleKernels:
         p = phi.numpy()
         p[:n_snk] = (p[:n_snk] if accumulate else 0.0) + w.sum(1)
 
+    def accel_pair(self, blk_a, n_a, blk_b, n_b, eps, G, acc_a, acc_b, accumulate, uniform_mass=False, phi_a=None, phi_b=None):
+        """Two different blocks: acc_a (+)= force of B on A, acc_b = force of A on B (the oracle, one direction at a time)."""
+        if phi_a is not None:
+            self.accel_pot(blk_a, n_a, blk_b, n_b, eps, G, acc_a, phi_a, accumulate, uniform_mass)
+            self.accel_pot(blk_b, n_b, blk_a, n_a, eps, G, acc_b, phi_b, False, uniform_mass)
+        else:
+            self.accel(blk_a, n_a, blk_b, n_b, eps, G, acc_a, accumulate, uniform_mass)
+            self.accel(blk_b, n_b, blk_a, n_a, eps, G, acc_b, False, uniform_mass)
+
     def pot_energy(self, phi, mass_row, n, eps, out, uniform_mass=False):
         m = mass_row.numpy().astype(np.float64)[:n]
         self_term = m / eps if eps > 0 else 0.0

@@ -23,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, mode, out_dir):
+def _worker(rank, world, port, n, mode, pairwise, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -32,8 +32,8 @@ def _worker(rank, world, port, n, mode, out_dir):
         eps, dt = 0.02, 1 / 128
         s = nb.plummer_sphere(n, 5)
         s.mass = s.mass * np.random.default_rng(1).uniform(0.5, 2.0, n)   # unequal masses
-        eng = nb.ShardedEngine(n, np.float64, device="cpu", kernels=OracleKernels(), mode=mode)
-        assert sum(eng.counts) == n and eng.n_loc == eng.counts[rank]
+        eng = nb.ShardedEngine(n, np.float64, device="cpu", kernels=OracleKernels(), mode=mode, pairwise=pairwise)
+        assert sum(eng.counts) == n and eng.n_loc == eng.counts[rank] and eng.pairwise == pairwise
         eng.set_state(s)
         from bachelor_thesis_n_body_amd.dist import HopProbe
         probe = HopProbe(torch, torch.device("cpu"))       # per-hop exchange timing (bench.py's `ring` block) on the host clock
@@ -43,7 +43,8 @@ def _worker(rank, world, port, n, mode, out_dir):
         probe.enabled = False
         if mode == "ring":
             ps = probe.summary()
-            assert ps["hops_timed"] == world - 1 and ps["comm_ms"] >= 0.0
+            # position hops: all P - 1 other chunks one-sidedly, or P // 2 with the pair-symmetric schedule (the other chunks' owners do the work)
+            assert ps["hops_timed"] == (world // 2 if pairwise else world - 1) and ps["comm_ms"] >= 0.0
         else:
             assert probe.summary() is None
         acc0 = eng.gather_state().acc
@@ -60,11 +61,16 @@ def _worker(rank, world, port, n, mode, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,mode", [(2, 96, "ring"), (2, 97, "allgather"), (3, 50, "ring"), (4, 131, "ring")])
-def test_sharded_engine_matches_single_process_oracle(tmp_path, world, n, mode):
+@pytest.mark.parametrize("world,n,mode,pairwise", [(2, 96, "ring", True), (2, 97, "allgather", True), (3, 50, "ring", True), (4, 131, "ring", True),
+                                                   (5, 77, "ring", True), (6, 80, "ring", True), (4, 61, "allgather", True), (5, 49, "allgather", True),
+                                                   (2, 96, "ring", False), (3, 50, "ring", False), (4, 131, "allgather", False)])
+def test_sharded_engine_matches_single_process_oracle(tmp_path, world, n, mode, pairwise):
+    """pairwise: every pair of chunks is worked on by one of its owners (two-sided kernel entry, partial sums sent back point to point; the
+    chunk half-way round an even ring one-sidedly) — worlds 3..6 cover one and two returned partials, the double-buffered partial and the
+    half-way hop; pairwise=False: every rank sums all chunks for its own sinks."""
     from oracle import nbody_oracle as ora
     import bachelor_thesis_n_body_amd as nb
-    mp.spawn(_worker, args=(world, _free_port(), n, mode, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, mode, pairwise, str(tmp_path)), nprocs=world, join=True)
     r = np.load(tmp_path / "res.npz")
     eps, dt = 0.02, 1 / 128
     s = nb.plummer_sphere(n, 5)

@@ -24,7 +24,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, mode, dtype_name, out_dir):
+def _worker(rank, world, port, n, mode, dtype_name, out_dir, force_sym=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -35,8 +35,11 @@ def _worker(rank, world, port, n, mode, dtype_name, out_dir):
         if dtype_name == "f64":
             s.mass = (s.mass * np.random.default_rng(1).uniform(0.5, 2.0, n)).astype(dtype)   # general-mass kernel
         eng = nb.ShardedEngine(n, dtype, device=torch.device("cuda", 0), mode=mode)
+        if force_sym:                # chunks this small would take the one-sided kernels: force the pair-symmetric ones (own chunk and two-block hops)
+            eng.k.set_option("sym_min_n", 0)
         eng.set_state(s)
         eng.accel(0.01)
+        assert eng.pairwise == (world > 1) and (not force_sym or eng.own_chunk_symmetric)
         acc0 = eng.gather_state().acc
         eng.step(1 / 256, 3, 0.01)
         st = eng.gather_state()
@@ -49,11 +52,14 @@ def _worker(rank, world, port, n, mode, dtype_name, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,mode,dtype_name", [(2, 6001, "ring", "f32"), (2, 4096, "allgather", "f64"), (4, 8191, "ring", "f32")])
-def test_two_ranks_on_one_gpu_match_the_single_engine(tmp_path, world, n, mode, dtype_name):
-    """2 and 4 ranks (uneven shards) sharing the one GPU of the box — at most 6 processes may use it."""
+@pytest.mark.parametrize("world,n,mode,dtype_name,force_sym", [(2, 6001, "ring", "f32", False), (2, 4096, "allgather", "f64", False), (4, 8191, "ring", "f32", False),
+                                                               (3, 24001, "ring", "f32", True), (4, 20000, "ring", "f64", True), (5, 30011, "allgather", "f32", True)])
+def test_two_ranks_on_one_gpu_match_the_single_engine(tmp_path, world, n, mode, dtype_name, force_sym):
+    """2 to 5 ranks (uneven shards) sharing the one GPU of the box — at most 6 processes may use it. From 3 ranks on the pair-symmetric
+    schedule has two-sided hops (nb_accel_pair_dev: the visiting chunk's partial sums travel back to its owner); force_sym runs them through
+    the pair-symmetric kernels although the chunks are small."""
     import bachelor_thesis_n_body_amd as nb
-    mp.spawn(_worker, args=(world, _free_port(), n, mode, dtype_name, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, mode, dtype_name, str(tmp_path), force_sym), nprocs=world, join=True)
     r = np.load(tmp_path / "res.npz")
     dtype = np.float32 if dtype_name == "f32" else np.float64
     s = nb.plummer_sphere(n, 5, dtype)
