@@ -36,6 +36,36 @@ static int use_device(nb_ctx* c) {
   return NB_OK;
 }
 
+// Two different blocks, every A-B pair once where the pair-symmetric kernels apply, otherwise the one-sided kernel in both directions.
+// A's arrays (+)= (NB_ACCUMULATE), B's are overwritten. Used by nb_accel_pair_dev and by the multi-device context.
+int nb_launch_accel_pair(nb_ctx* c, int dtype, const void* xa, const void* ya, const void* za, const void* ma, int64_t na,
+                         const void* xb, const void* yb, const void* zb, const void* mb, int64_t nb, double eps2, double G,
+                         void* aax, void* aay, void* aaz, void* bax, void* bay, void* baz, double* phi_a, double* phi_b, int flags) {
+  const int fl_b = flags & ~NB_ACCUMULATE;
+  int rc, taken = 0;
+  c->last_accel_sym = false;
+  if (dtype == NB_F32) {
+    rc = nb_launch_accel_cross_f32(c, (const float*)xa, (const float*)ya, (const float*)za, (const float*)ma, na, (const float*)xb, (const float*)yb,
+                                   (const float*)zb, (const float*)mb, nb, (float)eps2, (float)G, (float*)aax, (float*)aay, (float*)aaz,
+                                   (float*)bax, (float*)bay, (float*)baz, phi_a, phi_b, flags, &taken);
+    if (rc || taken) return rc;
+    rc = nb_launch_accel_f32(c, (const float*)xa, (const float*)ya, (const float*)za, na, (const float*)xb, (const float*)yb, (const float*)zb,
+                             (const float*)mb, nb, (float)eps2, (float)G, (float*)aax, (float*)aay, (float*)aaz, flags, phi_a);
+    if (rc) return rc;
+    return nb_launch_accel_f32(c, (const float*)xb, (const float*)yb, (const float*)zb, nb, (const float*)xa, (const float*)ya, (const float*)za,
+                               (const float*)ma, na, (float)eps2, (float)G, (float*)bax, (float*)bay, (float*)baz, fl_b, phi_b);
+  }
+  rc = nb_launch_accel_cross_f64(c, (const double*)xa, (const double*)ya, (const double*)za, (const double*)ma, na, (const double*)xb, (const double*)yb,
+                                 (const double*)zb, (const double*)mb, nb, eps2, G, (double*)aax, (double*)aay, (double*)aaz,
+                                 (double*)bax, (double*)bay, (double*)baz, phi_a, phi_b, flags, &taken);
+  if (rc || taken) return rc;
+  rc = nb_launch_accel_f64(c, (const double*)xa, (const double*)ya, (const double*)za, na, (const double*)xb, (const double*)yb, (const double*)zb,
+                           (const double*)mb, nb, eps2, G, (double*)aax, (double*)aay, (double*)aaz, flags, phi_a);
+  if (rc) return rc;
+  return nb_launch_accel_f64(c, (const double*)xb, (const double*)yb, (const double*)zb, nb, (const double*)xa, (const double*)ya, (const double*)za,
+                             (const double*)ma, na, eps2, G, (double*)bax, (double*)bay, (double*)baz, fl_b, phi_b);
+}
+
 extern "C" {
 
 int nb_version(void) { return 100; }
@@ -564,6 +594,7 @@ int nb_set_option(nb_ctx* c, int option, int64_t value) {
     case NB_OPT_SYM_SLAB_BYTES: c->sym_slab_bytes = v; break;
     default: return nb_fail(c, NB_ERR_ARG, "nb_set_option: unknown option");
   }
+  if (c->multi) return nb_multi_set_option(c, option, value);
   c->acc_valid = false;                               // the cached accelerations came from the other kernel's summation order
   if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }   // a captured step holds the old choice
   return NB_OK;
@@ -697,7 +728,6 @@ int nb_accel_pair_dev(nb_ctx* c, int dtype, const void* xa, const void* ya, cons
   if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_accel_pair_dev: unknown dtype");
   int rc = use_device(c); if (rc) return rc;
   c->last_accel_sym = false;
-  const int fl_b = flags & ~NB_ACCUMULATE;                    // B's arrays are overwritten
   if (na == 0 || nb == 0) {                                   // nothing to exchange: B's output is zero, A's untouched
     if (nb > 0) {
       const size_t bytes = (size_t)nb * esize(dtype);
@@ -706,27 +736,7 @@ int nb_accel_pair_dev(nb_ctx* c, int dtype, const void* xa, const void* ya, cons
     }
     return NB_OK;
   }
-  int taken = 0;
-  if (dtype == NB_F32) {
-    rc = nb_launch_accel_cross_f32(c, (const float*)xa, (const float*)ya, (const float*)za, (const float*)ma, na, (const float*)xb, (const float*)yb,
-                                   (const float*)zb, (const float*)mb, nb, (float)(eps * eps), (float)G, (float*)aax, (float*)aay, (float*)aaz,
-                                   (float*)bax, (float*)bay, (float*)baz, phi_a, phi_b, flags, &taken);
-    if (rc || taken) return rc;
-    rc = nb_launch_accel_f32(c, (const float*)xa, (const float*)ya, (const float*)za, na, (const float*)xb, (const float*)yb, (const float*)zb,
-                             (const float*)mb, nb, (float)(eps * eps), (float)G, (float*)aax, (float*)aay, (float*)aaz, flags, phi_a);
-    if (rc) return rc;
-    return nb_launch_accel_f32(c, (const float*)xb, (const float*)yb, (const float*)zb, nb, (const float*)xa, (const float*)ya, (const float*)za,
-                               (const float*)ma, na, (float)(eps * eps), (float)G, (float*)bax, (float*)bay, (float*)baz, fl_b, phi_b);
-  }
-  rc = nb_launch_accel_cross_f64(c, (const double*)xa, (const double*)ya, (const double*)za, (const double*)ma, na, (const double*)xb, (const double*)yb,
-                                 (const double*)zb, (const double*)mb, nb, eps * eps, G, (double*)aax, (double*)aay, (double*)aaz,
-                                 (double*)bax, (double*)bay, (double*)baz, phi_a, phi_b, flags, &taken);
-  if (rc || taken) return rc;
-  rc = nb_launch_accel_f64(c, (const double*)xa, (const double*)ya, (const double*)za, na, (const double*)xb, (const double*)yb, (const double*)zb,
-                           (const double*)mb, nb, eps * eps, G, (double*)aax, (double*)aay, (double*)aaz, flags, phi_a);
-  if (rc) return rc;
-  return nb_launch_accel_f64(c, (const double*)xb, (const double*)yb, (const double*)zb, nb, (const double*)xa, (const double*)ya, (const double*)za,
-                             (const double*)ma, na, eps * eps, G, (double*)bax, (double*)bay, (double*)baz, fl_b, phi_b);
+  return nb_launch_accel_pair(c, dtype, xa, ya, za, ma, na, xb, yb, zb, mb, nb, eps * eps, G, aax, aay, aaz, bax, bay, baz, phi_a, phi_b, flags);
 }
 
 int nb_pot_energy_dev(nb_ctx* c, int dtype, const double* phi, const void* m, int64_t n, double eps, int uniform, double* w_out) {

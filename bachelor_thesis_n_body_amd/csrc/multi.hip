@@ -15,6 +15,15 @@
 //   ev_kern[g][b]  recorded on g's stream after the kernel that read buffer b          -> the next pull into b waits for it
 //   ev_pulled[o][g] recorded on g's copy stream after pulling o's block                -> o's next drift waits for all of them
 // The same device may appear several times in dev_ids (a one-GPU rehearsal of the P-device schedule: tests/test_gpu_multi.py).
+//
+// Pair-symmetric schedule (default; NB_OPT_PAIR_SYMMETRY 0 restores the one above). Every pair of chunks is worked on by ONE of its two
+// owners: device g pulls only the blocks of owners g+1 .. g+(P-1)/2 and evaluates every (own, visiting) pair ONCE (nb_launch_accel_pair:
+// the two-block form of the pair-symmetric kernels), adding to its own sums and collecting the visitor's partial sums in a buffer that it
+// then PUSHES to the visitor's owner (hipMemcpyPeerAsync on its compute stream, behind the kernel); for an even P the block half-way round
+// is met from both sides one-sidedly; each owner finally adds the (P-1)/2 partials it was sent, in a fixed order. P/2 pulled blocks per
+// device instead of P-1, half the pair work. Two more events:
+//   ev_back[o][h]  recorded on the pusher's stream after the partial for owner o from hop h has landed   -> o's add waits for it
+//   ev_added[o]    recorded on o's stream after it has added its partials                                 -> the next push into o's buffers waits for it
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
 #include <vector>
@@ -32,6 +41,16 @@ struct nb_multi_state {
   std::vector<hipEvent_t> ev_pulled;                  // [owner][reader]
   std::vector<char> kern_valid;                       // ev_kern[g][b] has been recorded (also by an EARLIER force evaluation)
   std::vector<char> pulled_valid;                     // ev_pulled[o][g] has been recorded since o's positions last changed
+  // pair-symmetric schedule: H = (P - 1) / 2 returned partials per owner
+  int H = 0, R = 0;                                   // R = H + 1 for an even P: the chunk half-way round is split between its two owners
+  std::vector<void*> outb;                            // [P]   3 * n_max elements: the visiting chunk's partial accelerations
+  std::vector<double*> outphi;                        // [P]   n_max doubles (lazy: energy runs only)
+  std::vector<void*> back;                            // [P*R] 3 * n_max elements: partials of the own chunk returned by the devices that were handed it
+  std::vector<double*> backphi;                       // [P*R]
+  std::vector<hipEvent_t> ev_back;                    // [P*R]
+  std::vector<hipEvent_t> ev_added;                   // [P]
+  std::vector<char> added_valid;
+  long long pairwise = -1;                            // NB_OPT_PAIR_SYMMETRY of the context (-1: default = on)
   bool uniform = false;
   bool acc_valid = false;
   double acc_eps = -1.0, acc_G = 0.0;
@@ -82,6 +101,111 @@ int for_each_chunk(nb_ctx* c, F fn) {
   return NB_OK;
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) add_flat_kernel(T* __restrict__ a, const T* __restrict__ b, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}
+
+// The pair-symmetric schedule (file header): own chunk, then the chunks of owners g+1 .. g+H two-sidedly with the visitor's partial sums
+// pushed to its owner, then — P even — the chunk half-way round one-sidedly; finally every owner adds the partials it was sent.
+int refresh_acc_pairwise(nb_ctx* c, double eps, double G, bool with_phi) {
+  nb_multi_state& m = *c->multi;
+  const int P = m.P, H = m.H, R = m.R, hops = R;        // R = H (+ 1: the chunk half-way round an even ring, split between its two owners)
+  const size_t es = esz(c->dtype);
+  for (int g = 0; g < P; ++g) {
+    MHIP(c, hipSetDevice(m.dev[g]));
+    MHIP(c, hipEventRecord(m.ev_pos[g], m.shard[g]->stream));
+    if (with_phi && R > 0 && !m.outphi[g]) {
+      MHIP(c, hipMalloc((void**)&m.outphi[g], (size_t)m.n_max * sizeof(double)));
+      for (int h = 0; h < R; ++h) MHIP(c, hipMalloc((void**)&m.backphi[g * R + h], (size_t)m.n_max * sizeof(double)));
+    }
+  }
+  for (int h = 0; h <= hops; ++h) {
+    for (int g = 0; g < P; ++g) {
+      MHIP(c, hipSetDevice(m.dev[g]));
+      nb_ctx* s = m.shard[g];
+      if (h < hops) {                                    // pull the block of hop h+1 while hop h computes
+        const int o2 = (g + h + 1) % P, b = (h + 1) & 1;
+        void* dst = b ? m.recv1[g] : m.recv0[g];
+        MHIP(c, hipStreamWaitEvent(m.copy[g], m.ev_pos[o2], 0));
+        if (m.kern_valid[g * 2 + b]) MHIP(c, hipStreamWaitEvent(m.copy[g], m.ev_kern[g * 2 + b], 0));
+        MHIP(c, hipMemcpyPeerAsync(dst, m.dev[g], m.shard[o2]->state, m.dev[o2], 4 * (size_t)m.cnt[o2] * es, m.copy[g]));
+        MHIP(c, hipEventRecord(m.ev_copy[g * 2 + b], m.copy[g]));
+        MHIP(c, hipEventRecord(m.ev_pulled[o2 * P + g], m.copy[g]));
+        m.pulled_valid[o2 * P + g] = 1;
+      }
+      const int o = (g + h) % P, b = h & 1;
+      const char* src = reinterpret_cast<const char*>(h == 0 ? s->state : (b ? m.recv1[g] : m.recv0[g]));
+      if (h >= 1) MHIP(c, hipStreamWaitEvent(s->stream, m.ev_copy[g * 2 + b], 0));
+      const size_t so = (size_t)m.cnt[o] * es;
+      const int uni = m.uniform ? NB_UNIFORM_MASS : 0;
+      double* phi = with_phi ? s->phi : nullptr;
+      int rc;
+      if (h == 0) {                                      // own chunk (symmetric inside the launcher)
+        const int flags = (h == 0 ? 0 : NB_ACCUMULATE) | uni;
+        if (c->dtype == NB_F32)
+          rc = nb_launch_accel_f32(s, (const float*)field_ptr(s, 0), (const float*)field_ptr(s, 1), (const float*)field_ptr(s, 2), s->n,
+                                   (const float*)src, (const float*)(src + so), (const float*)(src + 2 * so), (const float*)(src + 3 * so), m.cnt[o],
+                                   (float)(eps * eps), (float)G, (float*)field_ptr(s, 7), (float*)field_ptr(s, 8), (float*)field_ptr(s, 9), flags, phi);
+        else
+          rc = nb_launch_accel_f64(s, (const double*)field_ptr(s, 0), (const double*)field_ptr(s, 1), (const double*)field_ptr(s, 2), s->n,
+                                   (const double*)src, (const double*)(src + so), (const double*)(src + 2 * so), (const double*)(src + 3 * so), m.cnt[o],
+                                   eps * eps, G, (double*)field_ptr(s, 7), (double*)field_ptr(s, 8), (double*)field_ptr(s, 9), flags, phi);
+        if (rc) return nb_fail(c, rc, std::string("multi: device ") + std::to_string(m.dev[g]) + ": " + s->err);
+      } else {                                           // every (own, visiting) pair once; the visitor's sums go to its owner
+        // hop <= H: the whole own chunk x the whole visiting chunk. The hop half-way round an even ring (h = H + 1) is shared with the
+        // visitor's owner: the lower device takes its own LOWER half x the whole visitor, the higher device its whole chunk x the visitor's
+        // UPPER half — together every pair of the two chunks once, half each.
+        int64_t a0 = 0, na = s->n, b0 = 0, nb = m.cnt[o];
+        if (h > H) { if (g < o) na = s->n / 2; else { b0 = m.cnt[o] / 2; nb = m.cnt[o] - b0; } }
+        const size_t ao = (size_t)a0 * es, bo = (size_t)b0 * es, sb = (size_t)nb * es;
+        char* ob = reinterpret_cast<char*>(m.outb[g]);
+        rc = nb_launch_accel_pair(s, c->dtype, field_ptr(s, 0) + ao, field_ptr(s, 1) + ao, field_ptr(s, 2) + ao, field_ptr(s, 3) + ao, na,
+                                  src + bo, src + so + bo, src + 2 * so + bo, src + 3 * so + bo, nb, eps * eps, G,
+                                  field_ptr(s, 7) + ao, field_ptr(s, 8) + ao, field_ptr(s, 9) + ao, ob, ob + sb, ob + 2 * sb,
+                                  phi, with_phi ? m.outphi[g] : nullptr, NB_ACCUMULATE | uni);
+        if (rc) return nb_fail(c, rc, std::string("multi: device ") + std::to_string(m.dev[g]) + ": " + s->err);
+        // o's buffers of this hop still hold the partial of the PREVIOUS evaluation until o has added it
+        if (m.added_valid[o]) MHIP(c, hipStreamWaitEvent(s->stream, m.ev_added[o], 0));
+        if (nb > 0) {
+          MHIP(c, hipMemcpyPeerAsync(m.back[o * R + h - 1], m.dev[o], ob, m.dev[g], 3 * sb, s->stream));
+          if (with_phi) MHIP(c, hipMemcpyPeerAsync(m.backphi[o * R + h - 1], m.dev[o], m.outphi[g], m.dev[g], (size_t)nb * sizeof(double), s->stream));
+        }
+        MHIP(c, hipEventRecord(m.ev_back[o * R + h - 1], s->stream));
+      }
+      if (h >= 1) { MHIP(c, hipEventRecord(m.ev_kern[g * 2 + b], s->stream)); m.kern_valid[g * 2 + b] = 1; }
+    }
+  }
+  for (int o = 0; o < P && R > 0; ++o) {                  // every owner adds what it was sent, hop 1 first: a fixed order
+    MHIP(c, hipSetDevice(m.dev[o]));
+    nb_ctx* s = m.shard[o];
+    auto add = [&](void* dst, const void* src, int64_t cnt) {
+      if (cnt <= 0) return;
+      if (c->dtype == NB_F32) add_flat_kernel<float><<<(int)((cnt + 255) / 256), 256, 0, s->stream>>>((float*)dst, (const float*)src, cnt);
+      else add_flat_kernel<double><<<(int)((cnt + 255) / 256), 256, 0, s->stream>>>((double*)dst, (const double*)src, cnt);
+    };
+    for (int h = 0; h < R; ++h) {
+      MHIP(c, hipStreamWaitEvent(s->stream, m.ev_back[o * R + h], 0));
+      if (h < H) {                                       // a partial for the whole chunk: [ax | ay | az] is one flat array of 3 n
+        add(field_ptr(s, 7), m.back[o * R + h], 3 * s->n);
+        if (with_phi && s->n > 0) add_flat_kernel<double><<<(int)((s->n + 255) / 256), 256, 0, s->stream>>>(s->phi, m.backphi[o * R + h], s->n);
+      } else {                                           // the half-way hop: the lower device is sent its UPPER half, the higher device its whole chunk
+        const int partner = (o + P / 2) % P;
+        const int64_t lo = o < partner ? s->n / 2 : 0, k = s->n - lo;
+        const char* bsrc = reinterpret_cast<const char*>(m.back[o * R + h]);
+        for (int f = 0; f < 3; ++f) add(field_ptr(s, 7 + f) + (size_t)lo * es, bsrc + (size_t)f * (size_t)k * es, k);
+        if (with_phi && k > 0) add_flat_kernel<double><<<(int)((k + 255) / 256), 256, 0, s->stream>>>(s->phi + lo, m.backphi[o * R + h], k);
+      }
+      MHIP(c, hipGetLastError());
+    }
+    MHIP(c, hipEventRecord(m.ev_added[o], s->stream));
+    m.added_valid[o] = 1;
+  }
+  m.acc_valid = true; m.acc_eps = eps; m.acc_G = G;
+  return NB_OK;
+}
+
 // owner o is about to change its positions: every pull of its block must have finished
 int wait_for_readers(nb_ctx* c, int o) {
   nb_multi_state& m = *c->multi;
@@ -97,6 +221,7 @@ int wait_for_readers(nb_ctx* c, int o) {
 int refresh_acc(nb_ctx* c, double eps, double G, bool with_phi = false) {
   nb_multi_state& m = *c->multi;
   const size_t es = esz(c->dtype);
+  if (m.P > 1 && m.pairwise != 0) return refresh_acc_pairwise(c, eps, G, with_phi);
   int rc = for_each_chunk(c, [&](int g, int o, const char* src, bool first) -> int {
     nb_ctx* s = m.shard[g];
     const size_t so = (size_t)m.cnt[o] * es;
@@ -141,6 +266,15 @@ void nb_multi_release(nb_ctx* c) {
     if (g < (int)m->recv1.size() && m->recv1[g]) (void)hipFree(m->recv1[g]);
     if (g < (int)m->copy.size() && m->copy[g]) (void)hipStreamDestroy(m->copy[g]);
     if (g < (int)m->ev_pos.size() && m->ev_pos[g]) (void)hipEventDestroy(m->ev_pos[g]);
+    if (g < (int)m->outb.size() && m->outb[g]) (void)hipFree(m->outb[g]);
+    if (g < (int)m->outphi.size() && m->outphi[g]) (void)hipFree(m->outphi[g]);
+    if (g < (int)m->ev_added.size() && m->ev_added[g]) (void)hipEventDestroy(m->ev_added[g]);
+    for (int h = 0; h < m->R; ++h) {
+      const size_t q = (size_t)g * m->R + h;
+      if (q < m->back.size() && m->back[q]) (void)hipFree(m->back[q]);
+      if (q < m->backphi.size() && m->backphi[q]) (void)hipFree(m->backphi[q]);
+      if (q < m->ev_back.size() && m->ev_back[q]) (void)hipEventDestroy(m->ev_back[q]);
+    }
     for (int b = 0; b < 2; ++b) {
       if (g * 2 + b < (int)m->ev_copy.size() && m->ev_copy[g * 2 + b]) (void)hipEventDestroy(m->ev_copy[g * 2 + b]);
       if (g * 2 + b < (int)m->ev_kern.size() && m->ev_kern[g * 2 + b]) (void)hipEventDestroy(m->ev_kern[g * 2 + b]);
@@ -166,6 +300,10 @@ int nb_multi_create(nb_ctx* c, int ndev, const int* dev_ids) {
   m->recv0.assign(ndev, nullptr); m->recv1.assign(ndev, nullptr); m->copy.assign(ndev, nullptr);
   m->ev_pos.assign(ndev, nullptr); m->ev_copy.assign(2 * ndev, nullptr); m->ev_kern.assign(2 * ndev, nullptr);
   m->ev_pulled.assign((size_t)ndev * ndev, nullptr); m->pulled_valid.assign((size_t)ndev * ndev, 0); m->kern_valid.assign(2 * (size_t)ndev, 0);
+  m->H = (ndev - 1) / 2;
+  m->R = ndev > 1 ? ndev / 2 : 0;
+  m->outb.assign(ndev, nullptr); m->outphi.assign(ndev, nullptr); m->ev_added.assign(ndev, nullptr); m->added_valid.assign(ndev, 0);
+  m->back.assign((size_t)ndev * m->R, nullptr); m->backphi.assign((size_t)ndev * m->R, nullptr); m->ev_back.assign((size_t)ndev * m->R, nullptr);
   const size_t es = esz(c->dtype);
   for (int g = 0; g < ndev; ++g) {
     int rc = nb_create(&m->shard[g], m->cnt[g], c->dtype, dev_ids[g]);
@@ -175,6 +313,14 @@ int nb_multi_create(nb_ctx* c, int ndev, const int* dev_ids) {
       MHIP(c, hipMalloc(&m->recv0[g], 4 * (size_t)m->n_max * es));
       MHIP(c, hipMalloc(&m->recv1[g], 4 * (size_t)m->n_max * es));
     }
+    if (m->R > 0) {
+      MHIP(c, hipMalloc(&m->outb[g], 3 * (size_t)m->n_max * es));
+      for (int h = 0; h < m->R; ++h) {
+        MHIP(c, hipMalloc(&m->back[(size_t)g * m->R + h], 3 * (size_t)m->n_max * es));
+        MHIP(c, hipEventCreateWithFlags(&m->ev_back[(size_t)g * m->R + h], hipEventDisableTiming));
+      }
+    }
+    MHIP(c, hipEventCreateWithFlags(&m->ev_added[g], hipEventDisableTiming));
     MHIP(c, hipStreamCreateWithFlags(&m->copy[g], hipStreamNonBlocking));
     MHIP(c, hipEventCreateWithFlags(&m->ev_pos[g], hipEventDisableTiming));
     for (int b = 0; b < 2; ++b) {
@@ -359,4 +505,17 @@ int nb_multi_info(const nb_ctx* c, int which, int64_t* out, int cap) {
   const nb_multi_state& m = *c->multi;
   for (int g = 0; g < m.P && g < cap; ++g) out[g] = which == 0 ? m.cnt[g] : (which == 1 ? m.off[g] : (int64_t)m.dev[g]);
   return m.P;
+}
+
+// options of the pair-symmetric kernels reach every shard; NB_OPT_PAIR_SYMMETRY also selects the schedule of this context
+int nb_multi_set_option(nb_ctx* c, int option, int64_t value) {
+  nb_multi_state& m = *c->multi;
+  int rc = sync_all(c); if (rc) return rc;
+  if (option == NB_OPT_PAIR_SYMMETRY) m.pairwise = value < 0 ? -1 : (long long)value;
+  for (int g = 0; g < m.P; ++g) {
+    rc = nb_set_option(m.shard[g], option, value);
+    if (rc) return nb_fail(c, rc, m.shard[g]->err);
+  }
+  m.acc_valid = false;
+  return NB_OK;
 }

@@ -89,6 +89,10 @@ int nb_launch_accel_cross_f64(nb_ctx* c, const double* xa, const double* ya, con
                               const double* xb, const double* yb, const double* zb, const double* mb, int64_t nb,
                               double eps2, double G, double* aax, double* aay, double* aaz, double* bax, double* bay, double* baz,
                               double* phi_a, double* phi_b, int flags, int* taken);
+// cross kernel where it applies, else the one-sided kernel in both directions (capi.hip)
+int nb_launch_accel_pair(nb_ctx* c, int dtype, const void* xa, const void* ya, const void* za, const void* ma, int64_t na,
+                         const void* xb, const void* yb, const void* zb, const void* mb, int64_t nb, double eps2, double G,
+                         void* aax, void* aay, void* aaz, void* bax, void* bay, void* baz, double* phi_a, double* phi_b, int flags);
 int nb_launch_accel_f64(nb_ctx* c, const double* xi, const double* yi, const double* zi, int64_t n_snk,
                         const double* xs, const double* ys, const double* zs, const double* ms, int64_t n_src,
                         double eps2, double G, double* ax, double* ay, double* az, int flags, double* phi = nullptr);
@@ -119,6 +123,7 @@ int nb_multi_kdk(nb_ctx* c, int64_t nsteps, const double* kick1, const double* d
 int nb_multi_energy(nb_ctx* c, double eps, double G, double* kinetic, double* potential);
 int nb_multi_step_energy(nb_ctx* c, double dt, int64_t nsteps, double eps, double G, double* kinetic, double* potential);
 int nb_multi_sync(nb_ctx* c);
+int nb_multi_set_option(nb_ctx* c, int option, int64_t value);
 int nb_multi_info(const nb_ctx* c, int which, int64_t* out, int cap);
 int nb_bh_check(nb_ctx* c);   // call after a stream sync
 int nb_launch_potential_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, const float* mi,

@@ -87,10 +87,10 @@ class HipKernels:
 
     @staticmethod
     def _rows(t, k):
-        assert t.is_contiguous() and t.shape[0] >= k
-        es, n = t.element_size(), t.shape[1]
-        base = t.data_ptr()
-        return [C.c_void_p(base + i * n * es) for i in range(k)]
+        """Device pointers of the first k rows of a [rows][n] block; a column range of such a block (rows still unit-stride) is fine too."""
+        assert t.dim() == 2 and t.shape[0] >= k and (t.shape[1] <= 1 or t.stride(1) == 1)
+        es, base = t.element_size(), t.data_ptr()
+        return [C.c_void_p(base + i * t.stride(0) * es) for i in range(k)]
 
     def accel(self, snk, n_snk, src, n_src, eps, G, acc, accumulate, uniform_mass=False):
         self._bind()
@@ -282,8 +282,12 @@ class ShardedEngine:
             pairwise = self.world > 1 and hasattr(kernels, "accel_pair") and self.virtual is None
         self.pairwise = bool(pairwise) and self.world > 1
         self.H = (self.world - 1) // 2 if self.pairwise else 0
-        self.out = [z(3, self.n_max), z(3, self.n_max)] if self.H > 0 else []
-        self.back = [z(3, self.n_max) for _ in range(self.H)]
+        # an even ring's chunk half-way round belongs to two ranks at once: each takes half of ITS pairs two-sidedly (the lower rank its own
+        # lower half against the whole visiting chunk, the higher rank its whole chunk against the visitor's upper half) and they swap partials
+        self.split_half = self.pairwise and self.world % 2 == 0 and self.virtual is None
+        nbuf = self.H + (1 if self.split_half else 0)
+        self.out = [z(3, self.n_max), z(3, self.n_max)] if nbuf > 0 else []
+        self.back = [z(3, self.n_max) for _ in range(nbuf)]
         self.out_phi, self.back_phi = [], []
         self.scal = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.phi = None                # per-sink potential of the fused force+potential kernels (step_with_energy)
@@ -399,7 +403,7 @@ class ShardedEngine:
         glob = (lambda k: dist.get_global_rank(self.group, k)) if self.group is not None else (lambda k: k)
         if with_potential and not self.out_phi:
             zf = lambda: t.zeros(self.n_max, dtype=t.float64, device=self.device)
-            self.out_phi, self.back_phi = [zf(), zf()], [zf() for _ in range(H)]
+            self.out_phi, self.back_phi = [zf(), zf()], [zf() for _ in range(len(self.back))]
 
         gather = None
         if self.mode == "allgather":
@@ -414,6 +418,21 @@ class ShardedEngine:
             owner = (r - h) % P
             if tm is not None:
                 tm.begin()
+            if h > H and self.split_half:                # the chunk half-way round: half of its pairs, two-sidedly (see __init__)
+                n_o = self.counts[owner]
+                if r < owner:                            # lower rank: own lower half x the whole visiting chunk
+                    n_lo = self.n_loc // 2
+                    self.k.accel_pair(self.pm[:, :n_lo], n_lo, cur, n_o, eps, G, self.acc[:, :n_lo], self.out[h & 1], True, self.uniform_mass,
+                                      self.phi[:n_lo] if with_potential else None, self.out_phi[h & 1] if with_potential else None)
+                    delivered = 2.0 * n_lo * n_o
+                else:                                    # higher rank: whole own chunk x the visitor's upper half
+                    lo_o = n_o // 2
+                    self.k.accel_pair(self.pm, self.n_loc, cur[:, lo_o:n_o], n_o - lo_o, eps, G, self.acc, self.out[h & 1], True, self.uniform_mass,
+                                      self.phi if with_potential else None, self.out_phi[h & 1] if with_potential else None)
+                    delivered = 2.0 * self.n_loc * (n_o - lo_o)
+                if tm is not None:
+                    tm.end(delivered)
+                return
             if h == 0 or h > H:                          # own chunk / the chunk half-way round: this rank's sinks only
                 if with_potential:
                     self.k.accel_pot(self.pm, self.n_loc, cur, self.counts[owner], eps, G, self.acc, self.phi, h > 0, self.uniform_mass)
@@ -428,7 +447,8 @@ class ShardedEngine:
                 tm.end(float(self.n_loc) * float(self.counts[owner]) * (2.0 if 0 < h <= H else 1.0))
 
         cur = self.pm
-        back_reqs = [None] * (H + 1)
+        back_reqs = [None] * (hops + 1)
+        two_sided = H + (1 if self.split_half else 0)    # hops 1 .. two_sided return a partial
         for h in range(hops + 1):
             reqs = None
             if h < hops and self.mode == "ring":
@@ -439,7 +459,7 @@ class ShardedEngine:
                 send_buf = cur if self.virtual is None else self.virtual[(r - h - 1) % P]
                 reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, send_buf, nxt_rank, self.group),
                                                dist.P2POp(dist.irecv, recv_buf, prv_rank, self.group)])   # posted before the kernel: runs beside it
-            if 2 <= h <= H and back_reqs[h - 2] is not None:  # the partial buffer of hop h - 2 is about to be overwritten: its send must be through
+            if 2 <= h <= two_sided and back_reqs[h - 2] is not None:  # the partial buffer of hop h - 2 is about to be overwritten: its send must be through
                 for q in back_reqs[h - 2]:
                     q.wait()
                 back_reqs[h - 2] = None
@@ -448,7 +468,7 @@ class ShardedEngine:
                 probe.exchange(reqs, lambda: kernel(h, cur), host_blocking=unordered or self.device.type != "cuda")
             else:
                 kernel(h, cur)
-            if 1 <= h <= H:                              # the visitor's partial goes to its owner; mine comes from the rank holding my chunk now
+            if 1 <= h <= two_sided:                      # the visitor's partial goes to its owner; mine comes from the rank holding my chunk now
                 fence()
                 if self.virtual is None:
                     to, frm, payload = glob((r - h) % P), glob((r + h) % P), self.out[h & 1]
@@ -485,6 +505,12 @@ class ShardedEngine:
             self.acc[:, : self.n_loc] += self.back[h - 1][:, : self.n_loc]
             if with_potential:
                 self.phi[: self.n_loc] += self.back_phi[h - 1][: self.n_loc]
+        if self.split_half:                              # what the rank half-way round worked out for this one
+            lo = self.n_loc // 2 if r < (r + P // 2) % P else 0        # the lower rank did its own lower half itself
+            k = self.n_loc - lo
+            self.acc[:, lo: self.n_loc] += self.back[H][:, :k]
+            if with_potential:
+                self.phi[lo: self.n_loc] += self.back_phi[H][:k]
 
     def accel(self, eps: float, G: float = 1.0, with_potential: bool = False) -> None:
         """acc <- a(x) of the owned sinks due to ALL particles; with_potential also accumulates self.phi over the chunks."""

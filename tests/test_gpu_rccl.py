@@ -23,15 +23,19 @@ CODE = textwrap.dedent("""
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        for dtype, P, n, general in ((np.float32, 2, 50001, False), (np.float32, 4, 131072, False), (np.float64, 3, 20011, True), (np.float32, 8, 65536, True)):
+        # pairwise: the pair-symmetric schedule (two-sided hops, the visiting chunk's partial sums sent back — here to itself — and the returned
+        # partials added at the end); what the ranks holding rank 0's chunk would return is computed locally in this one-rank rehearsal
+        for dtype, P, n, general, pairwise in ((np.float32, 2, 50001, False, False), (np.float32, 4, 131072, False, False), (np.float64, 3, 20011, True, False),
+                                               (np.float32, 8, 65536, True, False), (np.float32, 3, 150001, False, True), (np.float32, 8, 262144, False, True),
+                                               (np.float64, 5, 100003, True, True), (np.float32, 4, 40001, True, True)):
             s = nb.plummer_sphere(n, 7, dtype)
             if general:
                 s.mass = (s.mass * np.random.default_rng(2).uniform(0.5, 2.0, n)).astype(dtype)
             with nb.Engine(n, dtype) as e:
                 e.set_state(s)
                 ref = e.accel(0.01)
-            eng = nb.ShardedEngine(n, dtype, device=torch.device("cuda", 0), virtual_world=P)
-            assert dist.get_backend() == "nccl" and eng.world == P and eng.n_loc == eng.counts[0]
+            eng = nb.ShardedEngine(n, dtype, device=torch.device("cuda", 0), virtual_world=P, pairwise=pairwise)
+            assert dist.get_backend() == "nccl" and eng.world == P and eng.n_loc == eng.counts[0] and eng.pairwise == pairwise
             eng.set_state(s)
             probe = HopProbe(torch, torch.device("cuda", 0)); eng.hop_probe = probe; probe.enabled = True
             for rep in range(4):                      # repeated evaluations: every receive buffer is reused under the communicator's ordering
@@ -42,8 +46,8 @@ CODE = textwrap.dedent("""
             err = np.abs(got - ref[: eng.n_loc]).max() / np.abs(ref).max()
             assert err < tol, (dtype, P, err)
             ps = probe.summary()
-            assert ps["hops_timed"] == 4 * (P - 1) and ps["comm_ms"] > 0 and ps["kernel_ms"] > 0 and ps["exposed_ms"] >= 0
-            print("ok", np.dtype(dtype).name, P, n, "err %%.2e comm_ms %%.3f kernel_ms %%.3f exposed_ms %%.3f" %% (err, ps["comm_ms"], ps["kernel_ms"], ps["exposed_ms"]))
+            assert ps["hops_timed"] == 4 * (P // 2 if pairwise else P - 1) and ps["comm_ms"] > 0 and ps["kernel_ms"] > 0 and ps["exposed_ms"] >= 0
+            print("ok", np.dtype(dtype).name, P, n, "pairwise" if pairwise else "one-sided", "err %%.2e comm_ms %%.3f kernel_ms %%.3f exposed_ms %%.3f" %% (err, ps["comm_ms"], ps["kernel_ms"], ps["exposed_ms"]))
     finally:
         dist.destroy_process_group()
 """)
@@ -57,5 +61,5 @@ def test_rccl_ring_with_one_real_rank_playing_rank_zero_of_p():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", CODE % (str(ROOT), port)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
-    assert out.stdout.count("ok ") == 4, out.stdout
+    assert out.stdout.count("ok ") == 8, out.stdout
     print(out.stdout)
