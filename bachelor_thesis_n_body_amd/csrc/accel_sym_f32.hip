@@ -426,7 +426,7 @@ int nb_launch_accel_sym_f32(nb_ctx* c, const float* x, const float* y, const flo
                          env_ks = env_ll("NB_F32_SYM_KS", 0);
   const long long mode = c->sym_enable >= 0 ? c->sym_enable : env_mode, min_n = c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
                   budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
-  if (!mode || n < min_n || n >= (1ll << 31) || n <= BLOCK * 4) return NB_OK;
+  if (!mode || n < min_n || n >= (1ll << 31) - 65536 || n <= BLOCK * 4) return NB_OK;
   // Sinks per lane (set = 256 * KS particles). Equal masses, large n: 12 sinks x 1 source per step (244 VGPRs; fewest accumulator round trips
   // per pair: 159.6 ms at N = 2^20 against 163.7 with 8 sinks x 2 sources, one box); per-particle masses carry two more registers per sink
   // pair: 8 x 2. Smaller n: smaller sets, so that the launch still has a few thousand (set, offset) tiles to spread over 256 CUs.
@@ -456,7 +456,7 @@ int nb_launch_accel_cross_f32(nb_ctx* c, const float* xa, const float* ya, const
   const long long mode = c->sym_enable >= 0 ? c->sym_enable : env_mode, min_n = c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
                   budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
   const int64_t nmin = std::min(na, nb);
-  if (!mode || nmin * 2 < min_n || na >= (1ll << 31) || nb >= (1ll << 31) || nmin < 1) return NB_OK;   // (na x nb pairs ~ a self launch of sqrt(2 na nb))
+  if (!mode || nmin * 2 < min_n || na >= (1ll << 31) - 65536 || nb >= (1ll << 31) - 65536 || nmin < 1) return NB_OK;   // (na x nb pairs ~ a self launch of sqrt(2 na nb))
   auto tiles = [&](int ks) { const long long sa = (na + BLOCK * ks - 1) / (BLOCK * ks), sb = (nb + BLOCK * ks - 1) / (BLOCK * ks); return sa * sb; };
   const bool pot = phi_a != nullptr;
   int ks = (flags & NB_UNIFORM_MASS) && !pot ? 12 : 8;

@@ -319,7 +319,7 @@ int nb_launch_accel_sym_f64(nb_ctx* c, const double* x, const double* y, const d
                          env_ks = env_ll("NB_F64_SYM_KS", 0);
   const long long mode = c->sym_enable >= 0 ? c->sym_enable : env_mode, min_n = c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
                   budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
-  if (!mode || n < min_n || n >= (1ll << 31) || n <= BLOCK * 2) return NB_OK;
+  if (!mode || n < min_n || n >= (1ll << 31) - 65536 || n <= BLOCK * 2) return NB_OK;
   // sinks per lane: 8 for large n (N = 2^19, equal masses: 80.4 ms against 85.1 with 4 and 96.9 with 2; the one-sided kernel: 126.9), smaller
   // sets for smaller n so that the launch still has a few thousand (set, offset) tiles
   auto tiles = [&](int ks) { const long long ns = (n + BLOCK * ks - 1) / (BLOCK * ks); return ns * ((ns - 1) / 2 + 1); };
@@ -347,7 +347,7 @@ int nb_launch_accel_cross_f64(nb_ctx* c, const double* xa, const double* ya, con
   const long long mode = c->sym_enable >= 0 ? c->sym_enable : env_mode, min_n = c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
                   budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
   const int64_t nmin = std::min(na, nb);
-  if (!mode || nmin * 2 < min_n || na >= (1ll << 31) || nb >= (1ll << 31) || nmin < 1) return NB_OK;
+  if (!mode || nmin * 2 < min_n || na >= (1ll << 31) - 65536 || nb >= (1ll << 31) - 65536 || nmin < 1) return NB_OK;
   auto tiles = [&](int ks) { const long long sa = (na + BLOCK * ks - 1) / (BLOCK * ks), sb = (nb + BLOCK * ks - 1) / (BLOCK * ks); return sa * sb; };
   const bool pot = phi_a != nullptr;
   int ks = 8;

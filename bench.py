@@ -356,6 +356,7 @@ def main():
         clock_min = -float(t[1].item()) if clock_mhz else None
 
     symmetric = eng.k.last_accel_symmetric() if world == 1 else eng.own_chunk_symmetric
+    sym_all = symmetric and (world == 1 or eng.pairwise)       # N ranks: the pair-symmetric schedule makes every hop two-sided
     interactions = float(args.n) * float(args.n) * args.steps
     value = interactions / elapsed
     k_ms, k_inter, k_count = timer.summary()
@@ -386,7 +387,7 @@ def main():
             # compute stream still had to wait for (0 = hidden)
             "ring": probe.summary() if probe is not None else None,
             "roofline": {"bound": "vector_" + ("fp32" if args.dtype == "f32" else "fp64"),
-                         "kernel": ("accel_sym_%s_kernel" if (symmetric and world == 1) else "accel_%s_kernel") % args.dtype,
+                         "kernel": ("accel_sym_%s_kernel" if sym_all else "accel_%s_kernel") % args.dtype,
                          "variant": "uniform_mass" if eng.uniform_mass else "general",
                          # achieved = ORDERED interactions per launch x 20 flop / launch time — the convention the metric is quoted in
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -395,9 +396,10 @@ def main():
                          # N^2 ordered interactions are DELIVERED per launch, (N^2 + N * set) / 2 pair terms are EVALUATED, at 24 flop each
                          # (3 sub, 3 fma, rsqrt, 2 mul, 6 fma) = 12 flop per delivered interaction instead of the convention's 20
                          "pair_symmetry": bool(symmetric),
-                         "pair_symmetry_scope": (None if not symmetric else "every launch" if world == 1 else "own-chunk launch of each rank only"),
-                         "executed_flop_per_interaction": EXECUTED_FLOP_SYM if (symmetric and world == 1) else EXECUTED_FLOP_ONE_SIDED,
-                         "frac_executed_flops": achieved / peak * (EXECUTED_FLOP_SYM if (symmetric and world == 1) else EXECUTED_FLOP_ONE_SIDED) / FLOP_PER_INTERACTION,
+                         "pair_symmetry_scope": (None if not symmetric else "every launch" if sym_all else "own-chunk launch of each rank only"),
+                         "schedule": (None if world == 1 else "pair-symmetric: each pair of chunks worked on by one owner, partial sums returned" if eng.pairwise else "one-sided: every rank sums all chunks for its own sinks"),
+                         "executed_flop_per_interaction": EXECUTED_FLOP_SYM if sym_all else EXECUTED_FLOP_ONE_SIDED,
+                         "frac_executed_flops": achieved / peak * (EXECUTED_FLOP_SYM if sym_all else EXECUTED_FLOP_ONE_SIDED) / FLOP_PER_INTERACTION,
                          "interactions_per_launch": k_inter, "avg_launch_ms": k_ms, "launches_timed": k_count,
                          # rank 0's accel launches per step, back to back: what ms_per_step would be with a free exchange and free O(N) kernels
                          "kernel_ms_per_step": k_ms * k_count / max(1, args.steps),

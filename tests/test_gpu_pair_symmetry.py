@@ -195,10 +195,13 @@ def _phi_ref(snk, src, m, eps):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("general", [False, True])
-@pytest.mark.parametrize("na,nb_,force", [(40000, 33001, False), (3000, 7001, True), (1, 5000, True), (20000, 1025, True), (131072, 131072, False)])
+@pytest.mark.parametrize("na,nb_,force", [(40000, 33001, False), (3000, 7001, True), (1, 5000, True), (20000, 1025, True), (131072, 131072, False),
+                                          (3000, 7001, False), (30000, 26001, "passes")])
 def test_two_block_entry_matches_oracle(dtype, general, na, nb_, force, coracle):
     """acc_a (+)= force of B on A, acc_b = force of A on B, from ONE evaluation of every A-B pair; ragged and very unequal block sizes, the
-    accumulate flag of A, B overwritten; small blocks forced through the symmetric kernel with sym_min_n = 0."""
+    accumulate flag of A, B overwritten; small blocks forced through the symmetric kernel with sym_min_n = 0, or — not forced — through the
+    fallback (the one-sided kernel in both directions); "passes": a 1 MiB slab budget, i.e. several passes over ranges of A's sets with B's
+    sums accumulated between them."""
     import torch
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     s = _cloud(na + nb_, dtype, general, seed=21)
@@ -207,13 +210,15 @@ def test_two_block_entry_matches_oracle(dtype, general, na, nb_, force, coracle)
     k = nb.HipKernels(0)
     if force:
         k.set_option("sym_min_n", 0)
+    if force == "passes":
+        k.set_option("sym_slab_bytes", 1 << 20)
     blk = lambda lo, hi: torch.from_numpy(np.vstack([s.pos[lo:hi].T, s.mass[None, lo:hi]])).contiguous().cuda()
     A, B = blk(0, na), blk(na, na + nb_)
     acc_a = torch.full((3, na), 7.0, dtype=tdt, device="cuda")
     acc_b = torch.full((3, nb_), -3.0, dtype=tdt, device="cuda")
     k.accel_pair(A, na, B, nb_, 0.01, 1.3, acc_a, acc_b, False, uniform_mass=not general)
     took_sym = k.last_accel_symmetric()
-    assert took_sym == (min(na, nb_) >= 1 and (force or 2 * min(na, nb_) >= (32768 if dtype == np.float32 else 16384)))
+    assert took_sym == (min(na, nb_) >= 1 and (bool(force) or 2 * min(na, nb_) >= (32768 if dtype == np.float32 else 16384)))
     first = acc_a.clone()
     k.accel_pair(A, na, B, nb_, 0.01, 1.3, acc_a, acc_b, True, uniform_mass=not general)      # A accumulates, B is overwritten
     torch.cuda.synchronize()
