@@ -35,7 +35,7 @@ template <bool UNIFORM> __device__ inline d4 ld_src(const d4* p) {
 template <int KS, int TJ, bool GUARD, bool UNIFORM, bool POT>
 __global__ void __launch_bounds__(BLOCK)
 accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z, const double* __restrict__ m,
-                     int n, int nsets, int H, int o_begin, int o_end, int o_per_group, double eps2,
+                     int n, int nsets, int H, int o_begin, int o_end, int t_per_group, double eps2,
                      double* __restrict__ part, double* __restrict__ slab, size_t n_pad,
                      const double* __restrict__ xs, const double* __restrict__ ys, const double* __restrict__ zs, const double* __restrict__ ms,
                      int n_src, int nsets_src, size_t n_pad_src, int cross, int b0) {
@@ -71,9 +71,10 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
 
   for (int e = tid; e < WAVES * NC * AS; e += BLOCK) (&acc[0][0][0])[e] = 0.0;
 
-  const int o_lo = o_begin + blockIdx.y * o_per_group;
-  const int o_hi = min(o_end, o_lo + o_per_group);
-  const int ntiles = max(0, o_hi - o_lo) * QT;
+  // the (offset, tile of the set) pairs of this launch, o_begin * QT .. o_end * QT, are dealt to the groups y in runs of t_per_group
+  const int t_lo = o_begin * QT + blockIdx.y * t_per_group;
+  const int t_hi = min(o_end * QT, t_lo + t_per_group);
+  const int ntiles = max(0, t_hi - t_lo);
   auto set_of = [&](int o) {
     if (cross) return (b + o) % nsets_src;
     const int d = o <= H ? o : nsets / 2; int c = b + d; return c >= nsets ? c - nsets : c;
@@ -81,7 +82,7 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
 
   d4 stage[LPT];
   auto fetch = [&](int T) {
-    const int c = set_of(o_lo + T / QT), q = T % QT;
+    const int c = set_of((t_lo + T) / QT), q = (t_lo + T) % QT;
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
       const int j = c * SET + q * TJ + l * BLOCK + tid;
@@ -143,7 +144,7 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
   };
 
   for (int T = 0; T < ntiles; ++T) {
-    const int o = o_lo + T / QT, q = T % QT;
+    const int o = (t_lo + T) / QT, q = (t_lo + T) % QT;
     const bool sym = cross || (o >= 1 && o <= H);
     if (T + 1 < ntiles) fetch(T + 1);
     if (sym) walk(std::true_type{}); else walk(std::false_type{});
@@ -225,11 +226,12 @@ int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const 
   int slots_per_pass = (int)std::max<long long>(1, budget / (long long)slot_bytes);
   if (slots_per_pass > H) slots_per_pass = H > 0 ? H : 1;
   const int npass = H > 0 ? (H + slots_per_pass - 1) / slots_per_pass : 1;
+  constexpr int QT = SET / TJ;                               // tiles per set
   int groups_total = env_groups > 0 ? (int)env_groups : (4096 + nsets - 1) / nsets;
   if (groups_total < 1) groups_total = 1;
-  if (groups_total > n_o) groups_total = n_o;
-  const int opg = (n_o + groups_total - 1) / groups_total;
-  const int max_groups_pass = (slots_per_pass + 2 + opg - 1) / opg + 1;
+  if (groups_total > n_o * QT) groups_total = n_o * QT;
+  const int tpg = (n_o * QT + groups_total - 1) / groups_total;   // (offset, tile) pairs per group
+  const int max_groups_pass = ((slots_per_pass + 2) * QT + tpg - 1) / tpg + 1;
   const size_t part_bytes = (size_t)max_groups_pass * NC * n_pad * sizeof(double);
   const size_t slab_bytes = (size_t)slots_per_pass * slot_bytes;
   const size_t tot_bytes = npass > 1 ? NC * (size_t)n * sizeof(double) : 0;
@@ -245,12 +247,12 @@ int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const 
     const int s_begin = 1 + ps * slots_per_pass, s_end = 1 + std::min(H, (ps + 1) * slots_per_pass);
     const int o_begin = ps == 0 ? 0 : s_begin;
     const int o_end = (ps == npass - 1) ? n_o : s_end;
-    const int ngroups = (o_end - o_begin + opg - 1) / opg;
+    const int ngroups = ((o_end - o_begin) * QT + tpg - 1) / tpg;
     const int nslots = std::max(0, s_end - s_begin);
     if (ngroups > max_groups_pass) return nb_fail(c, NB_ERR_ARG, "accel_sym_f64: internal group count");
     dim3 grid(nsets, ngroups);
 #define NB_SYM_GO(GD, UF) accel_sym_f64_kernel<KS, TJ, GD, UF, POT><<<grid, BLOCK, 0, c->stream>>>( \
-    x, y, z, m, (int)n, nsets, H, o_begin, o_end, opg, eps2, part, slab, n_pad, x, y, z, m, (int)n, nsets, n_pad, 0, 0)
+    x, y, z, m, (int)n, nsets, H, o_begin, o_end, tpg, eps2, part, slab, n_pad, x, y, z, m, (int)n, nsets, n_pad, 0, 0)
     if (guard) { if (uniform) NB_SYM_GO(true, true); else NB_SYM_GO(true, false); }
     else       { if (uniform) NB_SYM_GO(false, true); else NB_SYM_GO(false, false); }
 #undef NB_SYM_GO
@@ -275,11 +277,12 @@ int run_cross(nb_ctx* c, const double* xa, const double* ya, const double* za, c
   const size_t slot_bytes = NC * npb * sizeof(double);
   int sets_per_pass = (int)std::max<long long>(1, budget / (long long)slot_bytes);
   if (sets_per_pass > nsa) sets_per_pass = nsa;
-  int groups = (4096 + sets_per_pass - 1) / sets_per_pass;
-  if (groups > nsb) groups = nsb;
+  constexpr int QT = SET / TJ;
+  int groups = (4096 + sets_per_pass - 1) / sets_per_pass;                  // ~4096 blocks per launch
+  if (groups > nsb * QT) groups = nsb * QT;
   if (groups < 1) groups = 1;
-  const int opg = (nsb + groups - 1) / groups;
-  groups = (nsb + opg - 1) / opg;
+  const int tpg = (nsb * QT + groups - 1) / groups;                         // (set of B, tile) pairs per group
+  groups = (nsb * QT + tpg - 1) / tpg;
   const size_t part_bytes = (size_t)groups * NC * npa * sizeof(double);
   int rc = nb_ensure_work(c, part_bytes + (size_t)sets_per_pass * slot_bytes);
   if (rc) return rc;
@@ -291,7 +294,7 @@ int run_cross(nb_ctx* c, const double* xa, const double* ya, const double* za, c
     const int nb_sets = std::min(sets_per_pass, nsa - b0);
     dim3 grid(nb_sets, groups);
 #define NB_SYM_GO(GD, UF) accel_sym_f64_kernel<KS, TJ, GD, UF, POT><<<grid, BLOCK, 0, c->stream>>>( \
-    xa, ya, za, ma, (int)na, nsa, 0, 0, nsb, opg, eps2, part, slab, npa, xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0)
+    xa, ya, za, ma, (int)na, nsa, 0, 0, nsb, tpg, eps2, part, slab, npa, xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0)
     if (guard) { if (uniform) NB_SYM_GO(true, true); else NB_SYM_GO(true, false); }
     else       { if (uniform) NB_SYM_GO(false, true); else NB_SYM_GO(false, false); }
 #undef NB_SYM_GO

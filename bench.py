@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="drive the N GPUs from THIS process through the C-ABI's multi-device context (nb_create_multi: peer pulls of the "
                          "source blocks, no torch.distributed); with --same-device all N shards sit on GPU 0 (rehearsal)")
+    ap.add_argument("--one-sided-schedule", action="store_true",
+                    help="N > 1: every rank sums all N chunks one-sidedly for its own sinks (rounds 1-2) instead of the pair-symmetric schedule (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="do not run the sustained-clock probe beside the timed region (for runs under rocprofv3 --pmc, which serialises kernels)")
@@ -313,7 +315,7 @@ def main():
     state = nb.plummer_sphere(args.n, seed=0, dtype=np_dtype)
     if args.general_mass:       # one mass 1 ulp up: same physics to ~1e-7/N, but no longer the equal-mass special case
         state.mass[-1] = np.nextafter(state.mass[-1], np_dtype(1.0))
-    eng = nb.ShardedEngine(args.n, np_dtype, device=device, mode=args.mode)
+    eng = nb.ShardedEngine(args.n, np_dtype, device=device, mode=args.mode, pairwise=False if args.one_sided_schedule else None)
     eng.set_state(state)
     timer = KernelTimer(torch)
     eng.kernel_timer = timer
