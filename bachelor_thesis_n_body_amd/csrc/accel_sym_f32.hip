@@ -432,11 +432,13 @@ int nb_launch_accel_sym_f32(nb_ctx* c, const float* x, const float* y, const flo
   if (!mode || n < min_n || n >= (1ll << 31) - 65536 || n <= BLOCK * 4) return NB_OK;
   // Sinks per lane (set = 256 * KS particles). Equal masses, large n: 12 sinks x 1 source per step (244 VGPRs; fewest accumulator round trips
   // per pair: 159.6 ms at N = 2^20 against 163.7 with 8 sinks x 2 sources, one box); per-particle masses carry two more registers per sink
-  // pair: 8 x 2. Smaller n: smaller sets, so that the launch still has a few thousand (set, offset) tiles to spread over 256 CUs.
-  auto tiles = [&](int ks) { const long long ns = (n + BLOCK * ks - 1) / (BLOCK * ks); return ns * ((ns - 1) / 2 + 1); };
+  // pair: 8 x 2. Smaller n: smaller sets, so that the launch still has enough (set, offset, tile) work items to spread over 256 CUs — measured
+  // (profiles/r03_sym_kernel_development_log.txt, sinks-per-lane sweep): 12 from ~3300 items (n ~ 100 000), 8 from ~700 (n ~ 36 000), else 4.
+  auto items = [&](int ks, int tj) { const long long ns = (n + BLOCK * ks - 1) / (BLOCK * ks); return ns * ((ns - 1) / 2 + 1) * (BLOCK * ks / tj); };
+  const int tj = phi ? 256 : 512;
   int ks = (flags & NB_UNIFORM_MASS) && !phi ? 12 : 8;
-  if (ks == 12 && tiles(12) < 2500) ks = 8;
-  if (ks == 8 && tiles(8) < 2500) ks = 4;
+  if (ks == 12 && items(12, tj) < 3300) ks = 8;
+  if (ks == 8 && items(8, tj) < 700) ks = 4;
   if (env_ks == 4 || env_ks == 8 || (env_ks == 12 && (flags & NB_UNIFORM_MASS) && !phi)) ks = (int)env_ks;
 #define NB_RUN(K, UU, PT) run_sym<K, UU, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups, phi)
   const int rc = phi ? (ks == 8 ? NB_RUN(8, 1, true) : NB_RUN(4, 2, true))
@@ -460,11 +462,12 @@ int nb_launch_accel_cross_f32(nb_ctx* c, const float* xa, const float* ya, const
                   budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
   const int64_t nmin = std::min(na, nb);
   if (!mode || nmin * 2 < min_n || na >= (1ll << 31) - 65536 || nb >= (1ll << 31) - 65536 || nmin < 1) return NB_OK;   // (na x nb pairs ~ a self launch of sqrt(2 na nb))
-  auto tiles = [&](int ks) { const long long sa = (na + BLOCK * ks - 1) / (BLOCK * ks), sb = (nb + BLOCK * ks - 1) / (BLOCK * ks); return sa * sb; };
   const bool pot = phi_a != nullptr;
-  int ks = (flags & NB_UNIFORM_MASS) && !pot ? 12 : 8;
-  if (ks == 12 && tiles(12) < 2500) ks = 8;
-  if (ks == 8 && tiles(8) < 2500) ks = 4;
+  const int tj = pot ? 256 : 512;
+  auto items = [&](int ks) { const long long sa = (na + BLOCK * ks - 1) / (BLOCK * ks), sb = (nb + BLOCK * ks - 1) / (BLOCK * ks); return sa * sb * (BLOCK * ks / tj); };
+  int ks = (flags & NB_UNIFORM_MASS) && !pot ? 12 : 8;      // as for a set on itself (nb_launch_accel_sym_f32)
+  if (ks == 12 && items(12) < 3300) ks = 8;
+  if (ks == 8 && items(8) < 700) ks = 4;
 #define NB_RUN(K, UU, PT) run_cross<K, UU, PT>(c, xa, ya, za, ma, na, xb, yb, zb, mb, nb, eps2, G, aax, aay, aaz, bax, bay, baz, phi_a, phi_b, flags, budget)
   const int rc = pot ? (ks == 8 ? NB_RUN(8, 1, true) : NB_RUN(4, 2, true))
                      : (ks == 12 ? NB_RUN(12, 1, false) : ks == 8 ? NB_RUN(8, 2, false) : NB_RUN(4, 2, false));

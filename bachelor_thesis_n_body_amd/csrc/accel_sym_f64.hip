@@ -324,11 +324,11 @@ int nb_launch_accel_sym_f64(nb_ctx* c, const double* x, const double* y, const d
                   budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
   if (!mode || n < min_n || n >= (1ll << 31) - 65536 || n <= BLOCK * 2) return NB_OK;
   // sinks per lane: 8 for large n (N = 2^19, equal masses: 80.4 ms against 85.1 with 4 and 96.9 with 2; the one-sided kernel: 126.9), smaller
-  // sets for smaller n so that the launch still has a few thousand (set, offset) tiles
-  auto tiles = [&](int ks) { const long long ns = (n + BLOCK * ks - 1) / (BLOCK * ks); return ns * ((ns - 1) / 2 + 1); };
+  // sets for smaller n so that the launch still has ~1000 (set, offset, tile) work items (sweep: profiles/r03_sym_kernel_development_log.txt)
+  auto items = [&](int ks) { const long long ns = (n + BLOCK * ks - 1) / (BLOCK * ks); return ns * ((ns - 1) / 2 + 1) * ks; };   // tile = 256: ks tiles per set
   int ks = 8;
-  if (tiles(8) < 2500) ks = 4;
-  if (ks == 4 && tiles(4) < 2500) ks = 2;
+  if (items(8) < 1000) ks = 4;
+  if (ks == 4 && items(4) < 1000) ks = 2;
   if (env_ks == 2 || env_ks == 4 || env_ks == 8) ks = (int)env_ks;
 #define NB_RUN(K, PT) run_sym<K, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups, phi)
   const int rc = phi ? (ks == 8 ? NB_RUN(8, true) : ks == 4 ? NB_RUN(4, true) : NB_RUN(2, true))
@@ -351,11 +351,11 @@ int nb_launch_accel_cross_f64(nb_ctx* c, const double* xa, const double* ya, con
                   budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
   const int64_t nmin = std::min(na, nb);
   if (!mode || nmin * 2 < min_n || na >= (1ll << 31) - 65536 || nb >= (1ll << 31) - 65536 || nmin < 1) return NB_OK;
-  auto tiles = [&](int ks) { const long long sa = (na + BLOCK * ks - 1) / (BLOCK * ks), sb = (nb + BLOCK * ks - 1) / (BLOCK * ks); return sa * sb; };
+  auto items = [&](int ks) { const long long sa = (na + BLOCK * ks - 1) / (BLOCK * ks), sb = (nb + BLOCK * ks - 1) / (BLOCK * ks); return sa * sb * ks; };
   const bool pot = phi_a != nullptr;
   int ks = 8;
-  if (tiles(8) < 2500) ks = 4;
-  if (ks == 4 && tiles(4) < 2500) ks = 2;
+  if (items(8) < 1000) ks = 4;
+  if (ks == 4 && items(4) < 1000) ks = 2;
 #define NB_RUN(K, PT) run_cross<K, PT>(c, xa, ya, za, ma, na, xb, yb, zb, mb, nb, eps2, G, aax, aay, aaz, bax, bay, baz, phi_a, phi_b, flags, budget)
   const int rc = pot ? (ks == 8 ? NB_RUN(8, true) : ks == 4 ? NB_RUN(4, true) : NB_RUN(2, true))
                      : (ks == 8 ? NB_RUN(8, false) : ks == 4 ? NB_RUN(4, false) : NB_RUN(2, false));

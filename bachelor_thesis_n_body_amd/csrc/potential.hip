@@ -3,7 +3,7 @@
 // 2 (index exclusion) per interaction; per-sink sums are flushed to fp64 at every tile boundary and the
 // block results are reduced in a fixed order (bit-reproducible).
 // The j == i exclusion is by GLOBAL particle index so that the same kernel serves the sink-decomposed
-// multi-GPU path, where sources arrive as chunks with an index offset.
+// multi-GPU path, where sources arrive as chunks with an index offset. A set on itself takes the upper triangle of tiles only.
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
 
@@ -28,7 +28,10 @@ potential_kernel(const T* __restrict__ xi, const T* __restrict__ yi, const T* __
                  const T* __restrict__ mi, int n_snk, long long snk_g0,
                  const T* __restrict__ xs, const T* __restrict__ ys, const T* __restrict__ zs,
                  const T* __restrict__ ms, int n_src, long long src_g0, int src_per_split, T eps2,
-                 double* __restrict__ part) {
+                 double* __restrict__ part, int tri) {
+  // tri: a set on itself (same arrays, same global offset). m_i m_j / r is symmetric, so only the source tiles on and above the sink
+  // block's own tile are walked (a sink block is exactly one tile wide): the tiles above count twice, the own tile — which holds
+  // both (i, j) and (j, i) — once. Half the pair work; the sums differ from the full sweep in rounding order only.
   constexpr int LPT = TILE / BLOCK;
   __shared__ vec4<T> tile[TILE];
   const int tid = threadIdx.x;
@@ -46,7 +49,11 @@ potential_kernel(const T* __restrict__ xi, const T* __restrict__ yi, const T* __
   }
   const int jbeg = blockIdx.y * src_per_split;
   const int jend = min(n_src, jbeg + src_per_split);
+  static_assert(TILE == BLOCK * KS, "the triangular sweep relies on sink block == one source tile");
   for (int jt = jbeg; jt < jend; jt += TILE) {
+    const int own = tri ? jt / TILE - (int)blockIdx.x : 1;      // < 0: below the diagonal, 0: the own tile, > 0: above
+    if (tri && own < 0) continue;
+    const double wgt = (tri && own > 0) ? 2.0 : 1.0;
     __syncthreads();
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
@@ -79,7 +86,7 @@ potential_kernel(const T* __restrict__ xi, const T* __restrict__ yi, const T* __
       }
     }
 #pragma unroll
-    for (int k = 0; k < KS; ++k) phi[k] += (double)acc[k];
+    for (int k = 0; k < KS; ++k) phi[k] += wgt * (double)acc[k];
   }
   // block reduction of sum_k m_i * phi_i
   double w = 0.0;
@@ -123,7 +130,8 @@ int launch_potential(nb_ctx* c, const T* xi, const T* yi, const T* zi, const T* 
   if (rc) return rc;
   double* part = reinterpret_cast<double*>(c->work);
   potential_kernel<T, TILE><<<dim3(nblk, nsplit), BLOCK, 0, c->stream>>>(
-      xi, yi, zi, mi, (int)n_snk, (long long)snk_g0, xs, ys, zs, ms, (int)n_src, (long long)src_g0, sps, eps2, part);
+      xi, yi, zi, mi, (int)n_snk, (long long)snk_g0, xs, ys, zs, ms, (int)n_src, (long long)src_g0, sps, eps2, part,
+      (xi == xs && yi == ys && zi == zs && mi == ms && n_snk == n_src && snk_g0 == src_g0) ? 1 : 0);
   NB_HIP(c, hipGetLastError());
   return nb_launch_final_sum(c, part, (int)nparts, 1.0, u_out, accumulate);
 }
