@@ -15,7 +15,7 @@
 //    distinct sets exactly once. d = 0 (a set with itself) and, for an even set count, d = nsets/2 (met from both sides) are walked
 //    one-sidedly (no second accumulation): 2 of nsets/2 + 1 tiles.
 //  * a set streams through LDS in tiles of TJ sources. In step t lane l of a wave meets source (t + l) mod TJ — every lane a DIFFERENT
-//    source, read with one conflict-free ds_read_b128 per lane (the tile carries 64 wrap-around copies, so the address is base + t).
+//    source, read with one conflict-free ds_read_b96 / b128 per lane (the tile carries 64 wrap-around copies, so the address is base + t).
 //    The lane adds the pair's term to its sinks in registers and the opposite term to the source's accumulator in LDS — a plain
 //    read / add / write of 64 different addresses per instruction: no conflicts, no reduction, no atomics (measured: the same walk
 //    with ds_add_f32 runs 6x slower — LDS float atomics retire a few lanes per clock). Each wave owns a private copy of the tile's
@@ -23,7 +23,8 @@
 //    complete in program order, so the sums are exact and bit-reproducible.
 //  * after a tile the block adds its waves' copies in a fixed order and stores the tile's partial accelerations to a slab
 //    [offset][3][n] (fp32, written once, no atomics); the sinks' own sums go to an fp64 slab [group][3][n]; a second kernel adds
-//    both in a fixed order. Slab traffic at N = 2^20: 3.2 GB written + read per launch (~1 ms of ~150).
+//    both in a fixed order. Slab traffic at N = 2^20 (12 sinks per lane): 2.4 GB written + 2.2 GB read per launch (PMC) — the reduce kernel
+//    takes 0.45 ms of a ~160 ms launch, the writes hide behind the math.
 //  * accuracy as accel_f32: fp32 partial sums live for one tile (sinks) / one set of 256*KS sinks (sources) and are then widened.
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
