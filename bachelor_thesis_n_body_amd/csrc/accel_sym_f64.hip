@@ -227,11 +227,10 @@ int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const 
   if (slots_per_pass > H) slots_per_pass = H > 0 ? H : 1;
   const int npass = H > 0 ? (H + slots_per_pass - 1) / slots_per_pass : 1;
   constexpr int QT = SET / TJ;                               // tiles per set
-  int groups_total = env_groups > 0 ? (int)env_groups : (4096 + nsets - 1) / nsets;
-  if (groups_total < 1) groups_total = 1;
-  if (groups_total > n_o * QT) groups_total = n_o * QT;
-  const int tpg = (n_o * QT + groups_total - 1) / groups_total;   // (offset, tile) pairs per group
-  const int max_groups_pass = ((slots_per_pass + 2) * QT + tpg - 1) / tpg + 1;
+  // groups: ~4096 blocks PER PASS (see accel_f32.hip's split sweep; a pass of a large problem must not shrink to a round or two of blocks)
+  int groups_target = env_groups > 0 ? (int)env_groups : (4096 + nsets - 1) / nsets;
+  if (groups_target < 1) groups_target = 1;
+  const int max_groups_pass = groups_target + 1;
   const size_t part_bytes = (size_t)max_groups_pass * NC * n_pad * sizeof(double);
   const size_t slab_bytes = (size_t)slots_per_pass * slot_bytes;
   const size_t tot_bytes = npass > 1 ? NC * (size_t)n * sizeof(double) : 0;
@@ -247,7 +246,9 @@ int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const 
     const int s_begin = 1 + ps * slots_per_pass, s_end = 1 + std::min(H, (ps + 1) * slots_per_pass);
     const int o_begin = ps == 0 ? 0 : s_begin;
     const int o_end = (ps == npass - 1) ? n_o : s_end;
-    const int ngroups = ((o_end - o_begin) * QT + tpg - 1) / tpg;
+    const int pass_tiles = (o_end - o_begin) * QT;             // (offset, tile) pairs of this pass, dealt to the groups in runs of tpg
+    const int tpg = std::max(1, (pass_tiles + groups_target - 1) / groups_target);
+    const int ngroups = (pass_tiles + tpg - 1) / tpg;
     const int nslots = std::max(0, s_end - s_begin);
     if (ngroups > max_groups_pass) return nb_fail(c, NB_ERR_ARG, "accel_sym_f64: internal group count");
     dim3 grid(nsets, ngroups);
