@@ -600,7 +600,11 @@ int nb_set_option(nb_ctx* c, int option, int64_t value) {
   return NB_OK;
 }
 
-int nb_last_accel_symmetric(const nb_ctx* c) { return c ? (c->last_accel_sym ? 1 : 0) : NB_ERR_ARG; }
+int nb_last_accel_symmetric(const nb_ctx* c) {
+  if (!c) return NB_ERR_ARG;
+  if (c->multi) return nb_multi_last_symmetric(c);          // the own-chunk launch of device 0
+  return c->last_accel_sym ? 1 : 0;
+}
 
 int nb_energy(nb_ctx* c, double eps, double G, double* kinetic, double* potential) {
   if (!c) return NB_ERR_ARG;

@@ -519,3 +519,10 @@ int nb_multi_set_option(nb_ctx* c, int option, int64_t value) {
   m.acc_valid = false;
   return NB_OK;
 }
+
+// 1 if the last force evaluation ran the pair-symmetric kernels (every launch of the pair-symmetric schedule ends with one; the one-sided
+// schedule only for the own chunk)
+int nb_multi_last_symmetric(const nb_ctx* c) {
+  const nb_multi_state& m = *c->multi;
+  return (m.P > 0 && m.shard[0] && m.shard[0]->last_accel_sym) ? 1 : 0;
+}

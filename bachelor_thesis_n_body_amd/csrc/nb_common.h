@@ -124,6 +124,7 @@ int nb_multi_energy(nb_ctx* c, double eps, double G, double* kinetic, double* po
 int nb_multi_step_energy(nb_ctx* c, double dt, int64_t nsteps, double eps, double G, double* kinetic, double* potential);
 int nb_multi_sync(nb_ctx* c);
 int nb_multi_set_option(nb_ctx* c, int option, int64_t value);
+int nb_multi_last_symmetric(const nb_ctx* c);
 int nb_multi_info(const nb_ctx* c, int which, int64_t* out, int cap);
 int nb_bh_check(nb_ctx* c);   // call after a stream sync
 int nb_launch_potential_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, const float* mi,

@@ -235,6 +235,7 @@ def single_process(args) -> int:
         t0 = time.perf_counter()
         eng.step(dt, args.steps, eps, G)          # ONE call: no host synchronisation between the steps; returns synchronised
         elapsed = time.perf_counter() - t0
+        symmetric = eng.last_accel_symmetric()
     value = float(args.n) * float(args.n) * args.steps / elapsed
     peak = PEAK_FP32_VECTOR_TFLOPS if args.dtype == "f32" else PEAK_FP64_VECTOR_TFLOPS
     achieved = value * FLOP_PER_INTERACTION / 1e12 / len(devices)
@@ -245,7 +246,9 @@ def single_process(args) -> int:
                       "parallelism": f"nb_create_multi: one process, sink-decomposition x{args.gpus}, peer pulls of source blocks",
                       "masses": "general (one mass perturbed by 1 ulp)" if args.general_mass else "equal"},
            "world_size": args.gpus, "backend": "hipMemcpyPeerAsync (single process)", "same_device": bool(args.same_device), "ring": None,
-           "roofline": {"bound": "vector_" + ("fp32" if args.dtype == "f32" else "fp64"), "kernel": "accel_%s_kernel" % args.dtype,
+           "roofline": {"bound": "vector_" + ("fp32" if args.dtype == "f32" else "fp64"),
+                        "kernel": ("accel_sym_%s_kernel" if symmetric else "accel_%s_kernel") % args.dtype, "pair_symmetry": bool(symmetric),
+                        "schedule": "pair-symmetric: each pair of chunks worked on by one owner, partial sums pushed to the other" if symmetric else "one-sided",
                         "variant": "general" if args.general_mass else "uniform_mass", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                         "frac": achieved / peak, "flop_per_interaction": FLOP_PER_INTERACTION,
                         "note": "per device, from the whole step (exchange and O(N) kernels included); kernel events are not visible from outside the library",
