@@ -383,7 +383,9 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"plummer_sphere N={args.n} {args.dtype} eps=0.01 dt=1/256, KDK step = 1 all-pairs force evaluation",
-                       "n": args.n, "parallelism": f"sink-decomposition x{world}, {args.mode} exchange of source chunks",
+                       "n": args.n, "parallelism": f"sink-decomposition x{world}, {args.mode} exchange of source chunks" + (
+                           f" ({world // 2} of {world - 1} hops: each pair of chunks is worked on by one of its owners, partial sums returned point to point)"
+                           if (world > 1 and eng.pairwise) else ""),
                        "masses": "general (one mass perturbed by 1 ulp)" if args.general_mass else "equal"},
             "world_size": world,
             "backend": (args.backend if args.backend == "gloo" else "nccl (RCCL)") if world > 1 else None,
