@@ -278,3 +278,20 @@ def test_two_block_entry_rejects_bad_arguments():
     with pytest.raises(RuntimeError, match="go together"):
         k.accel_pair(A, 100, A.clone(), 100, 0.01, 1.0, acc, acc.clone(), False, phi_a=torch.zeros(100, dtype=torch.float64, device="cuda"))
     k.close()
+
+
+@pytest.mark.parametrize("name", ["n40000_f32", "n40000_f64_general", "n100001_f32_general", "n100001_f64"])
+def test_symmetric_kernel_matches_committed_golden_vectors(name):
+    """The committed fixtures of this size class (tests/golden/accel_golden_large.npz: NumPy oracle, cross-checked against the C restatement when they
+    were generated) — no oracle at run time."""
+    from pathlib import Path
+    from test_golden import large_inputs
+    g = np.load(Path(__file__).resolve().parent / "golden" / "accel_golden_large.npz")
+    pos, mass = large_inputs(g, name)
+    n, dtype = len(mass), pos.dtype.type
+    with nb.Engine(n, dtype) as e:
+        e.set_state(nb.State(pos, np.zeros_like(pos), mass))
+        a = e.accel(float(g[f"{name}_eps"]), float(g[f"{name}_G"]))
+        assert e.last_accel_symmetric()
+    err = rel_err(a[g[f"{name}_idx"]], g[f"{name}_acc"])
+    assert err.max() < TOL[dtype], f"{name}: {err.max():.3e}"
