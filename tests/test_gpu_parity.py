@@ -259,11 +259,13 @@ def test_full_size_properties(dtype, n):
 
 # ------------------------------------------------------------------ hipGraph replay of the step loop
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_graph_replayed_steps_equal_eager_steps(dtype, monkeypatch):
+@pytest.mark.parametrize("n", [2000, 40000])
+def test_graph_replayed_steps_equal_eager_steps(dtype, n, monkeypatch):
     """nb_step replays a captured [kick_drift, accel] graph for steps 1..n-1 when N <= 65536 and nsteps >= 4;
     the state must be bit-identical to stepping one at a time (eager launches), also across calls that
-    interleave an energy evaluation (which may reallocate the scratch buffer the graph points into)."""
-    s = nb.plummer_sphere(2000, 23, dtype)
+    interleave an energy evaluation (which may reallocate the scratch buffer the graph points into).
+    n = 40000: the captured force evaluation is the pair-symmetric kernel + its slab reduction."""
+    s = nb.plummer_sphere(n, 23, dtype)
     with nb.Engine(s.n, dtype) as e:
         e.set_state(s)
         e.step(1 / 256, 7, 0.01)            # eager step 0 + 6 graph replays
