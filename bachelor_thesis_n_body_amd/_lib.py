@@ -18,6 +18,9 @@ NB_MESH_NO_INTERLACE, NB_MESH_LONG_ONLY, NB_MESH_SHORT_ONLY = 1, 2, 4
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libnbody_amd.so"
 
+# NB_OPT_* of include/nbody_amd.h (nb_set_option): the pair-symmetric all-pairs kernels
+OPTIONS = {"pair_symmetry": 1, "sym_min_n": 2, "sym_slab_bytes": 3}
+
 # every symbol include/nbody_amd.h declares: (name, restype, argtypes)
 _vp, _i64, _dbl, _int = C.c_void_p, C.c_int64, C.c_double, C.c_int
 SIGNATURES = {

@@ -105,12 +105,10 @@ class Engine:
         """True if the last kdk_run() replayed a captured hipGraph of one step (small-N, launch-bound runs)."""
         return bool(self._lib.nb_last_run_used_graph(self._ctx))
 
-    _OPTIONS = {"pair_symmetry": 1, "sym_min_n": 2, "sym_slab_bytes": 3}    # NB_OPT_* of include/nbody_amd.h
-
     def set_option(self, name: str, value: int) -> None:
         """Options of the pair-symmetric all-pairs kernels (nb_set_option): 'pair_symmetry' 0/1, 'sym_min_n', 'sym_slab_bytes'; value < 0
         restores the default."""
-        _lib.check(self._ctx, self._lib.nb_set_option(self._ctx, self._OPTIONS[name], int(value)), "nb_set_option")
+        _lib.check(self._ctx, self._lib.nb_set_option(self._ctx, _lib.OPTIONS[name], int(value)), "nb_set_option")
 
     def last_accel_symmetric(self) -> bool:
         """True if the last direct-summation force evaluation ran the pair-symmetric kernel (every unordered pair once)."""

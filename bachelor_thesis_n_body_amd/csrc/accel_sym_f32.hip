@@ -418,6 +418,16 @@ int run_cross(nb_ctx* c, const float* xa, const float* ya, const float* za, cons
   return NB_OK;
 }
 
+// options of the pair-symmetric kernels: the context's (nb_set_option) or, where unset, the process-wide defaults from the environment
+struct SymOpt { long long mode, min_n, budget, groups, ks; };
+SymOpt sym_options(const nb_ctx* c) {
+  static const long long env_mode = env_ll("NB_F32_SYM", 1), env_min_n = env_ll("NB_F32_SYM_MIN_N", 32768),
+                         env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_groups = env_ll("NB_F32_SYM_GROUPS", 0),
+                         env_ks = env_ll("NB_F32_SYM_KS", 0);
+  return SymOpt{c->sym_enable >= 0 ? c->sym_enable : env_mode, c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
+                c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_groups, env_ks};
+}
+
 }  // namespace
 
 // Self-interaction launch (sinks == sources). Returns NB_OK and sets *taken = 1 when the pair-symmetric kernel ran, *taken = 0 when the
@@ -426,11 +436,8 @@ int nb_launch_accel_sym_f32(nb_ctx* c, const float* x, const float* y, const flo
                             float eps2, float G, float* ax, float* ay, float* az, int flags, double* phi, int* taken) {
   *taken = 0;
   c->last_accel_sym = false;
-  static const long long env_mode = env_ll("NB_F32_SYM", 1), env_min_n = env_ll("NB_F32_SYM_MIN_N", 32768),
-                         env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_groups = env_ll("NB_F32_SYM_GROUPS", 0),
-                         env_ks = env_ll("NB_F32_SYM_KS", 0);
-  const long long mode = c->sym_enable >= 0 ? c->sym_enable : env_mode, min_n = c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
-                  budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
+  const SymOpt opt = sym_options(c);
+  const long long mode = opt.mode, min_n = opt.min_n, budget = opt.budget, env_groups = opt.groups, env_ks = opt.ks;
   if (!mode || n < min_n || n >= (1ll << 31) - 65536 || n <= BLOCK * 4) return NB_OK;
   // Sinks per lane (set = 256 * KS particles). Equal masses, large n: 12 sinks x 1 source per step (244 VGPRs; fewest accumulator round trips
   // per pair: 159.6 ms at N = 2^20 against 163.7 with 8 sinks x 2 sources, one box); per-particle masses carry two more registers per sink
@@ -459,9 +466,8 @@ int nb_launch_accel_cross_f32(nb_ctx* c, const float* xa, const float* ya, const
                               float eps2, float G, float* aax, float* aay, float* aaz, float* bax, float* bay, float* baz,
                               double* phi_a, double* phi_b, int flags, int* taken) {
   *taken = 0;
-  static const long long env_mode = env_ll("NB_F32_SYM", 1), env_min_n = env_ll("NB_F32_SYM_MIN_N", 32768), env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30);
-  const long long mode = c->sym_enable >= 0 ? c->sym_enable : env_mode, min_n = c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
-                  budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
+  const SymOpt opt = sym_options(c);
+  const long long mode = opt.mode, min_n = opt.min_n, budget = opt.budget;
   const int64_t nmin = std::min(na, nb);
   if (!mode || nmin * 2 < min_n || na >= (1ll << 31) - 65536 || nb >= (1ll << 31) - 65536 || nmin < 1) return NB_OK;   // (na x nb pairs ~ a self launch of sqrt(2 na nb))
   const bool pot = phi_a != nullptr;

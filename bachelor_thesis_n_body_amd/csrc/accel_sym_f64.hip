@@ -311,6 +311,16 @@ int run_cross(nb_ctx* c, const double* xa, const double* ya, const double* za, c
   return NB_OK;
 }
 
+// options of the pair-symmetric kernels: the context's (nb_set_option) or, where unset, the process-wide defaults from the environment
+struct SymOpt { long long mode, min_n, budget, groups, ks; };
+SymOpt sym_options(const nb_ctx* c) {
+  static const long long env_mode = env_ll("NB_F64_SYM", 1), env_min_n = env_ll("NB_F64_SYM_MIN_N", 16384),
+                         env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_groups = env_ll("NB_F64_SYM_GROUPS", 0),
+                         env_ks = env_ll("NB_F64_SYM_KS", 0);
+  return SymOpt{c->sym_enable >= 0 ? c->sym_enable : env_mode, c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
+                c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_groups, env_ks};
+}
+
 }  // namespace
 
 // Self-interaction launch (sinks == sources); *taken = 0: not applicable (small n, switched off with NB_F64_SYM=0) — use the one-sided kernel
@@ -318,11 +328,8 @@ int nb_launch_accel_sym_f64(nb_ctx* c, const double* x, const double* y, const d
                             double eps2, double G, double* ax, double* ay, double* az, int flags, double* phi, int* taken) {
   *taken = 0;
   c->last_accel_sym = false;
-  static const long long env_mode = env_ll("NB_F64_SYM", 1), env_min_n = env_ll("NB_F64_SYM_MIN_N", 16384),
-                         env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_groups = env_ll("NB_F64_SYM_GROUPS", 0),
-                         env_ks = env_ll("NB_F64_SYM_KS", 0);
-  const long long mode = c->sym_enable >= 0 ? c->sym_enable : env_mode, min_n = c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
-                  budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
+  const SymOpt opt = sym_options(c);
+  const long long mode = opt.mode, min_n = opt.min_n, budget = opt.budget, env_groups = opt.groups, env_ks = opt.ks;
   if (!mode || n < min_n || n >= (1ll << 31) - 65536 || n <= BLOCK * 2) return NB_OK;
   // sinks per lane: 8 for large n (N = 2^19, equal masses: 80.4 ms against 85.1 with 4 and 96.9 with 2; the one-sided kernel: 126.9), smaller
   // sets for smaller n so that the launch still has ~1000 (set, offset, tile) work items (sweep: profiles/r03_sym_kernel_development_log.txt)
@@ -347,9 +354,8 @@ int nb_launch_accel_cross_f64(nb_ctx* c, const double* xa, const double* ya, con
                               double eps2, double G, double* aax, double* aay, double* aaz, double* bax, double* bay, double* baz,
                               double* phi_a, double* phi_b, int flags, int* taken) {
   *taken = 0;
-  static const long long env_mode = env_ll("NB_F64_SYM", 1), env_min_n = env_ll("NB_F64_SYM_MIN_N", 16384), env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30);
-  const long long mode = c->sym_enable >= 0 ? c->sym_enable : env_mode, min_n = c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
-                  budget = c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget;
+  const SymOpt opt = sym_options(c);
+  const long long mode = opt.mode, min_n = opt.min_n, budget = opt.budget;
   const int64_t nmin = std::min(na, nb);
   if (!mode || nmin * 2 < min_n || na >= (1ll << 31) - 65536 || nb >= (1ll << 31) - 65536 || nmin < 1) return NB_OK;
   auto items = [&](int ks) { const long long sa = (na + BLOCK * ks - 1) / (BLOCK * ks), sb = (nb + BLOCK * ks - 1) / (BLOCK * ks); return sa * sb * ks; };

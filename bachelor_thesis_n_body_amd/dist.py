@@ -60,7 +60,7 @@ class HipKernels:
 
     def set_option(self, name: str, value: int) -> None:
         """nb_set_option on the launch context: 'pair_symmetry' 0/1, 'sym_min_n', 'sym_slab_bytes' (value < 0: default)."""
-        _lib.check(self._ctx, self._lib.nb_set_option(self._ctx, {"pair_symmetry": 1, "sym_min_n": 2, "sym_slab_bytes": 3}[name], int(value)),
+        _lib.check(self._ctx, self._lib.nb_set_option(self._ctx, _lib.OPTIONS[name], int(value)),
                    "nb_set_option")
 
     def last_accel_symmetric(self) -> bool:
