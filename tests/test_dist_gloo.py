@@ -63,11 +63,12 @@ def _worker(rank, world, port, n, mode, pairwise, out_dir):
 
 @pytest.mark.parametrize("world,n,mode,pairwise", [(2, 96, "ring", True), (2, 97, "allgather", True), (3, 50, "ring", True), (4, 131, "ring", True),
                                                    (5, 77, "ring", True), (6, 80, "ring", True), (4, 61, "allgather", True), (5, 49, "allgather", True),
+                                                   (7, 45, "ring", True), (8, 43, "ring", True),
                                                    (2, 96, "ring", False), (3, 50, "ring", False), (4, 131, "allgather", False)])
 def test_sharded_engine_matches_single_process_oracle(tmp_path, world, n, mode, pairwise):
     """pairwise: every pair of chunks is worked on by one of its owners (two-sided kernel entry, partial sums sent back point to point; the
-    chunk half-way round an even ring one-sidedly) — worlds 3..6 cover one and two returned partials, the double-buffered partial and the
-    half-way hop; pairwise=False: every rank sums all chunks for its own sinks."""
+    chunk half-way round an even ring split between its two owners) — worlds 3..8 cover one to three returned partials, the re-use of the two
+    partial buffers in flight and the half-way hop (8 ranks: the shape of the scaling run, chunks of 5-6 particles); pairwise=False: every rank sums all chunks for its own sinks."""
     from oracle import nbody_oracle as ora
     import bachelor_thesis_n_body_amd as nb
     mp.spawn(_worker, args=(world, _free_port(), n, mode, pairwise, str(tmp_path)), nprocs=world, join=True)
