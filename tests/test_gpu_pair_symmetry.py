@@ -122,12 +122,15 @@ def test_zero_softening_drops_coincident_pairs(dtype, coracle):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("general", [False, True])
-def test_fused_potential_of_the_symmetric_kernel(dtype, general):
+@pytest.mark.parametrize("budget", [-1, 1 << 21])
+def test_fused_potential_of_the_symmetric_kernel(dtype, general, budget):
     """nb_step_energy on a self-interacting set: the potential rides along in the pair-symmetric kernel (both particles of a pair get
-    m / r); compared with the separate potential kernel (nb_energy) and with the energies of the one-sided path."""
+    m / r); compared with the separate potential kernel (nb_energy) and with the energies of the one-sided path. budget = 2 MiB: the
+    evaluation takes several slab passes (accelerations AND potential collected in fp64 between them)."""
     n = 40000
     s = _cloud(n, dtype, general, seed=6)
     with _engine(n, dtype, s) as e:
+        e.set_option("sym_slab_bytes", budget)
         k1, u1 = e.step_with_energy(1.0 / 256, 3, 0.01)
         kk, uu = e.energy(0.01)
         st1 = e.get_state()
@@ -241,13 +244,16 @@ def test_two_block_entry_matches_oracle(dtype, general, na, nb_, force, coracle)
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("general", [False, True])
-def test_two_block_entry_fused_potential(dtype, general):
+@pytest.mark.parametrize("budget", [-1, 1 << 20])
+def test_two_block_entry_fused_potential(dtype, general, budget):
+    """budget = 1 MiB: several passes over ranges of A's sets, B's sums (accelerations and potential) accumulated between them."""
     import torch
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     na, nb_ = 9000, 12001
     s = _cloud(na + nb_, dtype, general, seed=23)
     k = nb.HipKernels(0)
     k.set_option("sym_min_n", 0)
+    k.set_option("sym_slab_bytes", budget)
     blk = lambda lo, hi: torch.from_numpy(np.vstack([s.pos[lo:hi].T, s.mass[None, lo:hi]])).contiguous().cuda()
     A, B = blk(0, na), blk(na, na + nb_)
     acc_a, acc_b = torch.zeros((3, na), dtype=tdt, device="cuda"), torch.zeros((3, nb_), dtype=tdt, device="cuda")
