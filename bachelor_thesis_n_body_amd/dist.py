@@ -230,7 +230,8 @@ class ShardedEngine:
                  pairwise=None):
         """pairwise (default: on for more than one rank when the kernel backend offers accel_pair): every pair of chunks is worked on by ONE of
         its two owners — rank r takes the chunks of ranks r-1 .. r-(P-1)//2 two-sidedly (nb_accel_pair_dev: each A-B pair evaluated once) and
-        sends the other owner its partial sums, point to point; for an even P the chunk half-way round is met from both sides one-sidedly.
+        sends the other owner its partial sums, point to point; for an even P the chunk half-way round is split between its two owners (the lower
+        rank takes its own lower half against the whole visitor, the higher rank its whole chunk against the visitor's upper half; they swap partials).
         The position ring then runs P//2 hops instead of P-1 and the pair work per rank halves (DESIGN.md §5.3). pairwise=False: every rank
         sums all P chunks one-sidedly for its own sinks (no accelerations travel).
         virtual_world = P > 1 (rehearsal on ONE GPU with the real transport): the process group has a single rank, which plays rank 0 of a
@@ -392,7 +393,8 @@ class ShardedEngine:
 
     def _accel_pairwise(self, eps: float, G: float, with_potential: bool) -> None:
         """The pair-symmetric schedule (see __init__): own chunk (symmetric inside the kernel), then the chunks of ranks r-1 .. r-H
-        two-sidedly with the partial sums sent back to their owners, then — P even — the chunk half-way round one-sidedly."""
+        two-sidedly with the partial sums sent back to their owners, then — P even — the chunk half-way round, whose pairs this rank shares
+        with that chunk's owner (half each, two-sidedly; one real rank playing P virtual ones: one-sidedly)."""
         t, dist = self._torch, self._dist
         P, r, H = self.world, self.rank, self.H
         half = P % 2 == 0
