@@ -405,6 +405,7 @@ def main():
                          "pair_symmetry": bool(symmetric),
                          "pair_symmetry_scope": (None if not symmetric else "every launch" if sym_all else "own-chunk launch of each rank only"),
                          "schedule": (None if world == 1 else "pair-symmetric: each pair of chunks worked on by one owner, partial sums returned" if eng.pairwise else "one-sided: every rank sums all chunks for its own sinks"),
+                         "pair_terms_evaluated_per_launch_approx": (k_inter / 2.0 if sym_all else k_inter),   # PMC count (one v_rsq per term): profiles/r03_*_rocprofv3_summary.txt
                          "executed_flop_per_interaction": EXECUTED_FLOP_SYM if sym_all else EXECUTED_FLOP_ONE_SIDED,
                          "frac_executed_flops": achieved / peak * (EXECUTED_FLOP_SYM if sym_all else EXECUTED_FLOP_ONE_SIDED) / FLOP_PER_INTERACTION,
                          "interactions_per_launch": k_inter, "avg_launch_ms": k_ms, "launches_timed": k_count,
