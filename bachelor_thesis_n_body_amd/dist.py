@@ -280,7 +280,9 @@ class ShardedEngine:
         # pair-symmetric schedule: partial sums of the visiting chunk (sent back to its owner; two buffers in flight) and the partials of the
         # own chunk returned by the (P-1)//2 ranks that were handed it
         if pairwise is None:
-            pairwise = self.world > 1 and hasattr(kernels, "accel_pair") and self.virtual is None
+            import os
+            pairwise = (self.world > 1 and hasattr(kernels, "accel_pair") and self.virtual is None
+                        and os.environ.get("NB_PAIRWISE_SCHEDULE", "1") != "0")         # NB_PAIRWISE_SCHEDULE=0: the one-sided schedule, without a code change
         self.pairwise = bool(pairwise) and self.world > 1
         self.H = (self.world - 1) // 2 if self.pairwise else 0
         # an even ring's chunk half-way round belongs to two ranks at once: each takes half of ITS pairs two-sidedly (the lower rank its own
