@@ -307,10 +307,10 @@ long long env_ll(const char* name, long long dflt) {
   return v && *v ? atoll(v) : dflt;
 }
 
-template <int KS, int U, bool POT, int TJ = POT ? 256 : 512>   // POT: a fourth accumulator per source — half the tile keeps the LDS footprint
+template <int KS, int U, bool POT>
 int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
             float eps2, float G, float* ax, float* ay, float* az, int flags, long long budget, long long env_groups, double* phi) {
-  constexpr int SET = BLOCK * KS, NC = POT ? 4 : 3;
+  constexpr int TJ = POT ? 256 : 512, SET = BLOCK * KS, NC = POT ? 4 : 3;   // POT: a fourth accumulator per source — half the tile keeps the LDS footprint
   const int nsets = (int)((n + SET - 1) / SET);
   const size_t n_pad = (size_t)nsets * SET;
   const int H = (nsets - 1) / 2;
@@ -450,11 +450,8 @@ int nb_launch_accel_sym_f32(nb_ctx* c, const float* x, const float* y, const flo
   if (ks == 8 && items(8, tj) < 700) ks = 4;
   if (env_ks == 4 || env_ks == 8 || (env_ks == 12 && (flags & NB_UNIFORM_MASS) && !phi)) ks = (int)env_ks;
 #define NB_RUN(K, UU, PT) run_sym<K, UU, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups, phi)
-  static const long long env_tj = env_ll("NB_F32_SYM_TJ", 0);        // experiment: 256-source tiles for the 8-sink kernel
   const int rc = phi ? (ks == 8 ? NB_RUN(8, 1, true) : NB_RUN(4, 2, true))
-                     : (ks == 12 ? NB_RUN(12, 1, false)
-                        : ks == 8 ? (env_tj == 256 ? run_sym<8, 2, false, 256>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups, phi) : NB_RUN(8, 2, false))
-                                  : NB_RUN(4, 2, false));
+                     : (ks == 12 ? NB_RUN(12, 1, false) : ks == 8 ? NB_RUN(8, 2, false) : NB_RUN(4, 2, false));
 #undef NB_RUN
   if (rc) return rc;
   *taken = 1;
