@@ -1,18 +1,29 @@
 """Sink-index decomposition over the GPUs of one node: one process per GPU under
 torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" for the CPU rehearsal in tests/).
 
-Rank g of P owns the contiguous sink range [off_g, off_g + cnt_g) and integrates only those particles. Every
-rank needs ALL sources, so each force evaluation circulates the (x, y, z, m) block of every rank once around
-a ring of P-1 hops: while the kernel works on the chunk that arrived at hop h, the chunk for hop h+1 is already
-in flight on the communicator's stream (send to rank+1 / receive from rank-1, posted BEFORE the kernel launch so
-the collective does not queue behind it). Accelerations need no reduction — each sink's sum completes locally;
-only the two energy scalars are all-reduced. One message = 16*cnt bytes (fp32) / 32*cnt bytes (fp64), i.e. 2 MiB
-per hop at N = 2^20 on 8 GPUs versus ~2-3 ms of math per chunk: the ring is hidden behind compute.
+Rank g of P owns the contiguous sink range [off_g, off_g + cnt_g) and integrates only those particles. Two schedules
+move the (x, y, z, m) blocks between the ranks:
+
+* one-sided (`pairwise=False`; the schedule SURVEY.md §8(e) / north_star name): every rank needs ALL sources, so each
+  force evaluation circulates the block of every rank once around a ring of P-1 hops: while the kernel works on the
+  chunk that arrived at hop h, the chunk for hop h+1 is already in flight on the communicator's stream (send to
+  rank+1 / receive from rank-1, posted BEFORE the kernel launch so the collective does not queue behind it).
+  Accelerations need no reduction — each sink's sum completes locally.
+* pair-symmetric (`pairwise=True`, the default for P > 1): every pair of chunks is worked on by ONE of its two
+  owners with the two-block kernel (each A-B pair evaluated once), so the position ring runs only P//2 hops — and
+  the visiting chunk's PARTIAL ACCELERATIONS TRAVEL BACK to its owner point to point (12 B per particle and hop,
+  posted while the next kernel runs) and are added in a fixed order at the end. Half the pair work per rank for one
+  extra message per hop; `ShardedEngine.set_schedule()` switches between the two on a live engine (bench.py times
+  both in one run).
+
+Only the two energy scalars are all-reduced. One position message = 16*cnt bytes (fp32) / 32*cnt bytes (fp64), i.e.
+2 MiB per hop at N = 2^20 on 8 GPUs versus ~2-3 ms of math per chunk: the ring is hidden behind compute.
 
 torch is used for device memory, streams and the process group only; all arithmetic is done by the HIP kernels
 behind the C-ABI (`HipKernels`). The compute backend is injectable so that the ring schedule, partitioning and
 buffer rotation can be exercised on CPU tensors with gloo (tests/ pass a NumPy stand-in; nothing in this package
-imports the oracle).
+imports the oracle). The transport of one hop sits in two overridable hooks (`_post_hop`, `_post_return`):
+tools/virtual_ring.py replaces them to rehearse a P-rank ring with ONE real RCCL rank.
 """
 from __future__ import annotations
 
@@ -166,8 +177,11 @@ class HipKernels:
 class HopProbe:
     """Per-hop timing of the ring: how long each exchange took (`comm_ms`, from the moment it was posted until its data
     had landed) next to the kernel it was posted beside (`kernel_ms`), and how long the compute stream then still had
-    to wait for it (`exposed_ms` — 0 when the hop is hidden behind the math). Device runs use HIP events: the post and
-    the kernel are bracketed on the compute stream; the arrival is observed on a side stream that waits for the
+    to wait for it (`exposed_ms` — 0 when the hop is hidden behind the math). The pair-symmetric schedule's return leg is
+    timed the same way: `back_comm_ms` (a partial-sum message from post to arrival), `back_exposed_ms` (what the compute
+    stream waited for returned partials, per force evaluation) and `add_ms` (the closing `acc += back[h]` adds, per force
+    evaluation) — so a gap between `kernel_ms_per_step` and `ms_per_step` can be attributed. Device runs use HIP events:
+    the post and the kernel are bracketed on the compute stream; the arrival is observed on a side stream that waits for the
     communicator's work only, so it does not include the kernel. Host-blocking transports (gloo) and CPU rehearsals
     fall back to the host clock around `wait()`."""
 
@@ -178,6 +192,10 @@ class HopProbe:
         self.side = torch.cuda.Stream(device) if self.cuda else None
         self.enabled = False
         self.hops = []      # per hop: (post, comm_done, kernel_begin, kernel_end, after_wait)
+        self.backs = []     # per returned partial: (post, arrived)
+        self.back_waits = []   # (before, after) of every wait for a returned partial on the compute stream
+        self.closings = []  # per force evaluation: (adds_begin, adds_end)
+        self.evals = 0
 
     def _mark(self, stream=None):
         if not self.cuda:
@@ -210,6 +228,35 @@ class HopProbe:
         self._hold = self._mark()
         self._host_post = self._clock()
 
+    def returning(self, post_mark, reqs, host_blocking):
+        """A partial-sum message has just been posted (`post_mark` = posting mark taken before it): observe its arrival on the side stream."""
+        if self.cuda and not host_blocking:
+            with self._t.cuda.stream(self.side):
+                for q in reqs:
+                    q.wait()
+                self.backs.append((post_mark, self._mark(self.side)))
+        else:
+            self._pending_back = getattr(self, "_pending_back", {})
+            self._pending_back[id(reqs)] = self._clock()
+
+    def wait_back(self, reqs):
+        """Wait for a returned partial on the compute stream (host for blocking transports) and record what the wait cost."""
+        w0 = self._mark()
+        for q in reqs:
+            q.wait()
+        w1 = self._mark()
+        self.back_waits.append((w0, w1))
+        t0 = getattr(self, "_pending_back", {}).pop(id(reqs), None)
+        if t0 is not None:
+            self.backs.append((t0, self._clock()))
+
+    def closing(self, fn):
+        """Run the closing adds of one force evaluation between two marks."""
+        a0 = self._mark()
+        fn()
+        self.closings.append((a0, self._mark()))
+        self.evals += 1
+
     def summary(self):
         """Means over the recorded hops (call after a device synchronise)."""
         if not self.hops:
@@ -219,38 +266,38 @@ class HopProbe:
         kern = [ms(k0, k1) for _, _, k0, k1, _ in self.hops] if self.cuda else [float("nan")] * len(self.hops)
         expo = [max(0.0, ms(k1, a)) for _, _, _, k1, a in self.hops] if self.cuda else [float("nan")] * len(self.hops)
         mean = lambda v: sum(v) / len(v)
-        return {"hops_timed": len(self.hops), "comm_ms": mean(comm), "kernel_ms": mean(kern), "exposed_ms": mean(expo),
-                "comm_ms_max": max(comm)}
+        out = {"hops_timed": len(self.hops), "comm_ms": mean(comm), "kernel_ms": mean(kern), "exposed_ms": mean(expo),
+               "comm_ms_max": max(comm)}
+        if self.backs or self.closings:
+            back = [ms(p, d) for p, d in self.backs]
+            ev = max(1, self.evals)
+            out.update({"returns_timed": len(back), "back_comm_ms": mean(back) if back else 0.0, "back_comm_ms_max": max(back) if back else 0.0,
+                        # per force evaluation: what the compute stream (host, for a blocking transport) waited for returned partials, and the closing adds
+                        "back_exposed_ms": sum(max(0.0, ms(a, b)) for a, b in self.back_waits) / ev,
+                        "add_ms": sum(ms(a, b) for a, b in self.closings) / ev, "evaluations_timed": self.evals})
+        return out
 
 
 class ShardedEngine:
     """Sink-decomposed engine of one rank. All ranks must make the same sequence of calls."""
 
-    def __init__(self, n_total: int, dtype=np.float32, device=None, group=None, kernels=None, mode: str = "ring", virtual_world: int = 0,
-                 pairwise=None):
-        """pairwise (default: on for more than one rank when the kernel backend offers accel_pair): every pair of chunks is worked on by ONE of
-        its two owners — rank r takes the chunks of ranks r-1 .. r-(P-1)//2 two-sidedly (nb_accel_pair_dev: each A-B pair evaluated once) and
-        sends the other owner its partial sums, point to point; for an even P the chunk half-way round is split between its two owners (the lower
-        rank takes its own lower half against the whole visitor, the higher rank its whole chunk against the visitor's upper half; they swap partials).
-        The position ring then runs P//2 hops instead of P-1 and the pair work per rank halves (DESIGN.md §5.3). pairwise=False: every rank
-        sums all P chunks one-sidedly for its own sinks (no accelerations travel).
-        virtual_world = P > 1 (rehearsal on ONE GPU with the real transport): the process group has a single rank, which plays rank 0 of a
-        P-rank ring — it owns the first of P sink ranges, holds the other ranks' source blocks locally, and at every hop sends the block its
-        predecessor would have sent TO ITSELF through the communicator (RCCL supports a send/receive pair on one rank). Everything the
-        RCCL path relies on is then exercised for real — batch_isend_irecv posted before the kernel, the communicator stream's ordering against the
-        compute stream, wait(), receive-buffer reuse — except the xGMI link. Only accel() / local_acc() make sense in this mode."""
+    def __init__(self, n_total: int, dtype=np.float32, device=None, group=None, kernels=None, mode: str = "ring", pairwise=None, world=None):
+        """pairwise (default: on for more than one rank when the kernel backend offers accel_pair; NB_PAIRWISE_SCHEDULE=0 in the environment
+        turns the default off; the ranks agree on the flag with a MIN all-reduce, so a rank that sees another environment cannot post a
+        different message sequence): every pair of chunks is worked on by ONE of its two owners — rank r takes the chunks of ranks
+        r-1 .. r-(P-1)//2 two-sidedly (nb_accel_pair_dev: each A-B pair evaluated once) and sends the other owner its partial sums, point to
+        point; for an even P the chunk half-way round is split between its two owners (the lower rank takes its own lower half against the
+        whole visitor, the higher rank its whole chunk against the visitor's upper half; they swap partials). The position ring then runs
+        P//2 hops instead of P-1 and the pair work per rank halves (DESIGN.md §5.3). pairwise=False: every rank sums all P chunks
+        one-sidedly for its own sinks (no accelerations travel). `world` is for subclasses that play several ranks with one real one
+        (tools/virtual_ring.py)."""
         import torch
         import torch.distributed as dist
 
         self._torch, self._dist = torch, dist
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.virtual = None
-        if virtual_world and virtual_world > 1:
-            if not dist.is_initialized() or self.world != 1 or mode != "ring":
-                raise ValueError("virtual_world needs an initialised single-rank process group and mode='ring'")
-            self.world = int(virtual_world)
+        self.world = int(world) if world else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.n_total = int(n_total)
         self.counts, self.offsets = partition(self.n_total, self.world)
         self.n_loc, self.off = self.counts[self.rank], self.offsets[self.rank]
@@ -268,30 +315,15 @@ class ShardedEngine:
                 raise RuntimeError("ShardedEngine needs a HIP device (or an injected `kernels` backend for CPU rehearsal)")
             kernels = HipKernels(self.device.index or 0)
         self.k = kernels
-        z = lambda *s: torch.zeros(*s, dtype=self.t_dtype, device=self.device)
+        self._z = lambda *s: torch.zeros(*s, dtype=self.t_dtype, device=self.device)
+        z = self._z
         # every block is padded to n_max columns so that all ring messages have one size
         self.pm = z(4, self.n_max)     # x y z m of the owned sinks == this rank's source chunk
         self.vel = z(3, self.n_max)
         self.acc = z(3, self.n_max)
         self.ring = [z(4, self.n_max), z(4, self.n_max)] if self.world > 1 else []
-        if virtual_world and virtual_world > 1:
-            self.virtual = z(self.world, 4, self.n_max)      # the source blocks of the other (virtual) ranks
         self.gathered = z(self.world, 4, self.n_max) if (self.world > 1 and mode == "allgather") else None
-        # pair-symmetric schedule: partial sums of the visiting chunk (sent back to its owner; two buffers in flight) and the partials of the
-        # own chunk returned by the (P-1)//2 ranks that were handed it
-        if pairwise is None:
-            import os
-            pairwise = (self.world > 1 and hasattr(kernels, "accel_pair") and self.virtual is None
-                        and os.environ.get("NB_PAIRWISE_SCHEDULE", "1") != "0")         # NB_PAIRWISE_SCHEDULE=0: the one-sided schedule, without a code change
-        self.pairwise = bool(pairwise) and self.world > 1
-        self.H = (self.world - 1) // 2 if self.pairwise else 0
-        # an even ring's chunk half-way round belongs to two ranks at once: each takes half of ITS pairs two-sidedly (the lower rank its own
-        # lower half against the whole visiting chunk, the higher rank its whole chunk against the visitor's upper half) and they swap partials
-        self.split_half = self.pairwise and self.world % 2 == 0 and self.virtual is None
-        nbuf = self.H + (1 if self.split_half else 0)
-        self.out = [z(3, self.n_max), z(3, self.n_max)] if nbuf > 0 else []
-        self.back = [z(3, self.n_max) for _ in range(nbuf)]
-        self.out_phi, self.back_phi = [], []
+        self.out, self.back, self.out_phi, self.back_phi = [], [], [], []
         self.scal = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.phi = None                # per-sink potential of the fused force+potential kernels (step_with_energy)
         self._acc_key = None
@@ -299,6 +331,39 @@ class ShardedEngine:
         self.own_chunk_symmetric = False   # the last accel() ran the pair-symmetric kernel on this rank's own chunk (HIP backend only)
         self.kernel_timer = None   # optional object with begin()/end(interactions): brackets every accel launch
         self.hop_probe = None      # optional HopProbe: per-hop exchange time next to the kernel it overlaps
+        self.heartbeat = None      # optional callable(label): called as the schedule advances (bench.py's stall watchdog)
+        if pairwise is None:
+            import os
+            pairwise = self.world > 1 and hasattr(kernels, "accel_pair") and os.environ.get("NB_PAIRWISE_SCHEDULE", "1") != "0"
+        self.set_schedule(self._agree(bool(pairwise)))
+
+    # -- schedule -------------------------------------------------------------------------------
+    def _agree(self, flag: bool) -> bool:
+        """The ranks must post the same message sequence: take the MIN of the flag over the group (a rank that resolved the default from a
+        different environment would otherwise deadlock the others in batch_isend_irecv instead of failing with an error)."""
+        dist = self._dist
+        if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return flag
+        t = self._torch.tensor([1 if flag else 0], dtype=self._torch.int32,
+                               device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
+    def set_schedule(self, pairwise: bool) -> None:
+        """Switch a live engine between the pair-symmetric and the one-sided schedule (same call on every rank). State is kept; the cached
+        accelerations stay valid (both schedules produce them). Buffers of the return leg are allocated the first time they are needed."""
+        self.pairwise = bool(pairwise) and self.world > 1
+        self.H = (self.world - 1) // 2 if self.pairwise else 0
+        # an even ring's chunk half-way round belongs to two ranks at once: each takes half of ITS pairs two-sidedly (the lower rank its own
+        # lower half against the whole visiting chunk, the higher rank its whole chunk against the visitor's upper half) and they swap partials
+        self.split_half = self.pairwise and self.world % 2 == 0
+        nbuf = self.H + (1 if self.split_half else 0)
+        # partial sums of the visiting chunk (sent back to its owner; two buffers in flight) and the partials of the own chunk returned by the
+        # ranks that were handed it
+        if nbuf > 0 and not self.out:
+            self.out = [self._z(3, self.n_max), self._z(3, self.n_max)]
+        while len(self.back) < nbuf:
+            self.back.append(self._z(3, self.n_max))
 
     # -- state ----------------------------------------------------------------------------------
     def set_state(self, state: State) -> None:
@@ -317,13 +382,6 @@ class ShardedEngine:
         self.uniform_mass = bool(m_all.size > 0 and np.all(m_all == m_all.flat[0]))
         self.pm.copy_(t.from_numpy(pm))
         self.vel.copy_(t.from_numpy(vel))
-        if self.virtual is not None:
-            allpm = np.zeros((self.world, 4, self.n_max), self.np_dtype)
-            for o in range(self.world):
-                so = slice(self.offsets[o], self.offsets[o] + self.counts[o])
-                allpm[o, :3, : self.counts[o]] = np.asarray(state.pos)[so].T
-                allpm[o, 3, : self.counts[o]] = np.asarray(state.mass)[so]
-            self.virtual.copy_(t.from_numpy(allpm))
         self._acc_key = None
 
     def gather_state(self) -> State:
@@ -344,6 +402,45 @@ class ShardedEngine:
         st.acc = np.ascontiguousarray(cat(acc, slice(0, 3))) if self._acc_key is not None else None
         return st
 
+    # -- transport of one hop (overridden by tools/virtual_ring.py) ---------------------------------
+    def _glob(self, k: int) -> int:
+        return self._dist.get_global_rank(self.group, k) if self.group is not None else k
+
+    def _unordered(self) -> bool:
+        """RCCL/NCCL collectives are ordered after the work already enqueued on the compute stream, so a receive into a buffer the
+        previous kernel is still reading is safe. Other backends (gloo moving device tensors: the one-GPU rehearsal of
+        tests/test_gpu_dist.py) give no such ordering: the compute stream is drained before every exchange there."""
+        return self.device.type == "cuda" and self._dist.get_backend(self.group) != "nccl"
+
+    def _fence(self) -> None:
+        if self._unordered():
+            self._torch.cuda.current_stream(self.device).synchronize()
+
+    def _post_hop(self, h: int, cur):
+        """Position hop h: the block in hand goes on to rank + 1, the block of rank r - h - 1 arrives from rank - 1. Returns (requests,
+        receive buffer); posted BEFORE the kernel that works on `cur` so that it runs beside it."""
+        dist = self._dist
+        P, r = self.world, self.rank
+        recv_buf = self.ring[h & 1]
+        ops = [dist.P2POp(dist.isend, cur, self._glob((r + 1) % P), self.group),
+               dist.P2POp(dist.irecv, recv_buf, self._glob((r - 1) % P), self.group)]
+        return dist.batch_isend_irecv(ops), recv_buf
+
+    def _post_return(self, h: int, eps: float, G: float, with_potential: bool):
+        """Return leg of two-sided hop h: the visitor's partial sums (self.out[h & 1]) go to their owner, rank r - h; this rank's partial
+        comes from the rank that holds ITS chunk at this hop, rank r + h, into self.back[h - 1]."""
+        dist = self._dist
+        P, r = self.world, self.rank
+        to, frm = self._glob((r - h) % P), self._glob((r + h) % P)
+        ops = [dist.P2POp(dist.isend, self.out[h & 1], to, self.group), dist.P2POp(dist.irecv, self.back[h - 1], frm, self.group)]
+        if with_potential:
+            ops += [dist.P2POp(dist.isend, self.out_phi[h & 1], to, self.group), dist.P2POp(dist.irecv, self.back_phi[h - 1], frm, self.group)]
+        return dist.batch_isend_irecv(ops)
+
+    def _beat(self, label: str) -> None:
+        if self.heartbeat is not None:
+            self.heartbeat(label)
+
     # -- force evaluation -----------------------------------------------------------------------
     def _for_each_chunk(self, fn) -> None:
         """Call fn(src_block, owner_rank, first) for the own chunk and then every other rank's chunk."""
@@ -352,13 +449,9 @@ class ShardedEngine:
         if P == 1:
             fn(self.pm, r, True)
             return
-        # RCCL/NCCL collectives are ordered after the work already enqueued on the compute stream, so a receive into a buffer the
-        # previous kernel is still reading is safe. Other backends (gloo moving device tensors: the one-GPU rehearsal of
-        # tests/test_gpu_dist.py) give no such ordering: drain the compute stream before every exchange there.
-        unordered = self.device.type == "cuda" and dist.get_backend(self.group) != "nccl"
-        fence = (lambda: self._torch.cuda.current_stream(self.device).synchronize()) if unordered else (lambda: None)
+        host_blocking = self._unordered() or self.device.type != "cuda"
         if self.mode == "allgather":
-            fence()
+            self._fence()
             work = dist.all_gather_into_tensor(self.gathered.view(-1), self.pm.view(-1), group=self.group, async_op=True)
             fn(self.pm, r, True)          # own chunk overlaps the collective
             work.wait()
@@ -366,25 +459,17 @@ class ShardedEngine:
                 o = (r - h) % P
                 fn(self.gathered[o], o, False)
             return
-        nxt_rank, prv_rank = (r + 1) % P, (r - 1) % P
-        if self.virtual is not None:
-            nxt_rank = prv_rank = dist.get_rank(self.group)          # the one real rank sends to itself what its predecessor would send
-        if self.group is not None:
-            nxt_rank, prv_rank = dist.get_global_rank(self.group, nxt_rank), dist.get_global_rank(self.group, prv_rank)
         cur = self.pm
         for h in range(P):
             reqs = None
             if h < P - 1:
-                fence()
+                self._fence()
                 if self.hop_probe is not None and self.hop_probe.enabled:
                     self.hop_probe.posting()
-                recv_buf = self.ring[h & 1]
-                send_buf = cur if self.virtual is None else self.virtual[(r - h - 1) % P]
-                ops = [dist.P2POp(dist.isend, send_buf, nxt_rank, self.group), dist.P2POp(dist.irecv, recv_buf, prv_rank, self.group)]
-                reqs = dist.batch_isend_irecv(ops)   # posted before the kernel so it runs beside it
+                reqs, recv_buf = self._post_hop(h, cur)
             probe = self.hop_probe if (reqs is not None and self.hop_probe is not None and self.hop_probe.enabled) else None
             if probe is not None:
-                probe.exchange(reqs, lambda: fn(cur, (r - h) % P, h == 0), host_blocking=unordered or self.device.type != "cuda")
+                probe.exchange(reqs, lambda: fn(cur, (r - h) % P, h == 0), host_blocking=host_blocking)
                 cur = recv_buf
                 continue
             fn(cur, (r - h) % P, h == 0)
@@ -396,27 +481,23 @@ class ShardedEngine:
     def _accel_pairwise(self, eps: float, G: float, with_potential: bool) -> None:
         """The pair-symmetric schedule (see __init__): own chunk (symmetric inside the kernel), then the chunks of ranks r-1 .. r-H
         two-sidedly with the partial sums sent back to their owners, then — P even — the chunk half-way round, whose pairs this rank shares
-        with that chunk's owner (half each, two-sidedly; one real rank playing P virtual ones: one-sidedly)."""
+        with that chunk's owner (half each, two-sidedly)."""
         t, dist = self._torch, self._dist
         P, r, H = self.world, self.rank, self.H
         half = P % 2 == 0
         hops = H + (1 if half else 0)                  # chunks that have to arrive
         tm = self.kernel_timer
-        unordered = self.device.type == "cuda" and dist.get_backend(self.group) != "nccl"
-        fence = (lambda: t.cuda.current_stream(self.device).synchronize()) if unordered else (lambda: None)
-        glob = (lambda k: dist.get_global_rank(self.group, k)) if self.group is not None else (lambda k: k)
-        if with_potential and not self.out_phi:
+        host_blocking = self._unordered() or self.device.type != "cuda"
+        if with_potential and len(self.back_phi) < len(self.back):
             zf = lambda: t.zeros(self.n_max, dtype=t.float64, device=self.device)
-            self.out_phi, self.back_phi = [zf(), zf()], [zf() for _ in range(len(self.back))]
+            self.out_phi = self.out_phi or [zf(), zf()]
+            while len(self.back_phi) < len(self.back):
+                self.back_phi.append(zf())
 
         gather = None
         if self.mode == "allgather":
-            fence()
+            self._fence()
             gather = dist.all_gather_into_tensor(self.gathered.view(-1), self.pm.view(-1), group=self.group, async_op=True)
-        if self.virtual is not None:
-            nxt_rank = prv_rank = glob(dist.get_rank(self.group))
-        else:
-            nxt_rank, prv_rank = glob((r + 1) % P), glob((r - 1) % P)
 
         def kernel(h, cur):
             owner = (r - h) % P
@@ -437,12 +518,12 @@ class ShardedEngine:
                 if tm is not None:
                     tm.end(delivered)
                 return
-            if h == 0 or h > H:                          # own chunk / the chunk half-way round: this rank's sinks only
+            if h == 0:                                   # own chunk: this rank's sinks only (pair-symmetric inside the kernel)
                 if with_potential:
-                    self.k.accel_pot(self.pm, self.n_loc, cur, self.counts[owner], eps, G, self.acc, self.phi, h > 0, self.uniform_mass)
+                    self.k.accel_pot(self.pm, self.n_loc, cur, self.counts[owner], eps, G, self.acc, self.phi, False, self.uniform_mass)
                 else:
-                    self.k.accel(self.pm, self.n_loc, cur, self.counts[owner], eps, G, self.acc, h > 0, self.uniform_mass)
-                if h == 0 and hasattr(self.k, "last_accel_symmetric"):
+                    self.k.accel(self.pm, self.n_loc, cur, self.counts[owner], eps, G, self.acc, False, self.uniform_mass)
+                if hasattr(self.k, "last_accel_symmetric"):
                     self.own_chunk_symmetric = self.k.last_accel_symmetric()
             else:                                        # every pair of (own chunk, visiting chunk) once; the visitor's sums go home
                 self.k.accel_pair(self.pm, self.n_loc, cur, self.counts[owner], eps, G, self.acc, self.out[h & 1], True, self.uniform_mass,
@@ -450,46 +531,39 @@ class ShardedEngine:
             if tm is not None:                           # interactions DELIVERED by the launch: both directions of a two-sided hop
                 tm.end(float(self.n_loc) * float(self.counts[owner]) * (2.0 if 0 < h <= H else 1.0))
 
+        hp = self.hop_probe if (self.hop_probe is not None and self.hop_probe.enabled) else None
+
+        def wait_back(reqs):
+            if hp is not None:
+                hp.wait_back(reqs)
+            else:
+                for q in reqs:
+                    q.wait()
+
         cur = self.pm
         back_reqs = [None] * (hops + 1)
         two_sided = H + (1 if self.split_half else 0)    # hops 1 .. two_sided return a partial
         for h in range(hops + 1):
             reqs = None
             if h < hops and self.mode == "ring":
-                fence()
-                if self.hop_probe is not None and self.hop_probe.enabled:
-                    self.hop_probe.posting()
-                recv_buf = self.ring[h & 1]
-                send_buf = cur if self.virtual is None else self.virtual[(r - h - 1) % P]
-                reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, send_buf, nxt_rank, self.group),
-                                               dist.P2POp(dist.irecv, recv_buf, prv_rank, self.group)])   # posted before the kernel: runs beside it
+                self._fence()
+                if hp is not None:
+                    hp.posting()
+                reqs, recv_buf = self._post_hop(h, cur)
             if 2 <= h <= two_sided and back_reqs[h - 2] is not None:  # the partial buffer of hop h - 2 is about to be overwritten: its send must be through
-                for q in back_reqs[h - 2]:
-                    q.wait()
+                wait_back(back_reqs[h - 2])
                 back_reqs[h - 2] = None
-            probe = self.hop_probe if (reqs is not None and self.hop_probe is not None and self.hop_probe.enabled) else None
+            probe = hp if reqs is not None else None
             if probe is not None:
-                probe.exchange(reqs, lambda: kernel(h, cur), host_blocking=unordered or self.device.type != "cuda")
+                probe.exchange(reqs, lambda: kernel(h, cur), host_blocking=host_blocking)
             else:
                 kernel(h, cur)
             if 1 <= h <= two_sided:                      # the visitor's partial goes to its owner; mine comes from the rank holding my chunk now
-                fence()
-                if self.virtual is None:
-                    to, frm, payload = glob((r - h) % P), glob((r + h) % P), self.out[h & 1]
-                    payload_phi = self.out_phi[h & 1] if with_potential else None
-                else:                                    # one real rank: what rank r + h would send is computed here and sent to itself
-                    to = frm = glob(dist.get_rank(self.group))
-                    o = (r + h) % P
-                    payload = t.zeros_like(self.out[0])
-                    scratch = t.zeros_like(self.out[0])
-                    payload_phi = t.zeros(self.n_max, dtype=t.float64, device=self.device) if with_potential else None
-                    self.k.accel_pair(self.virtual[o], self.counts[o], self.pm, self.n_loc, eps, G, scratch, payload, False, self.uniform_mass,
-                                      t.zeros_like(payload_phi) if with_potential else None, payload_phi)
-                    fence()
-                ops = [dist.P2POp(dist.isend, payload, to, self.group), dist.P2POp(dist.irecv, self.back[h - 1], frm, self.group)]
-                if with_potential:
-                    ops += [dist.P2POp(dist.isend, payload_phi, to, self.group), dist.P2POp(dist.irecv, self.back_phi[h - 1], frm, self.group)]
-                back_reqs[h] = dist.batch_isend_irecv(ops)
+                self._fence()
+                mark = hp._mark() if hp is not None else None
+                back_reqs[h] = self._post_return(h, eps, G, with_potential)
+                if hp is not None:
+                    hp.returning(mark, back_reqs[h], host_blocking)
             if probe is None and reqs is not None:
                 for q in reqs:
                     q.wait()
@@ -501,20 +575,26 @@ class ShardedEngine:
                         gather.wait()
                         gather = None
                     cur = self.gathered[(r - h - 1) % P]
+            self._beat("hop %d" % h)
         for reqs in back_reqs:
             if reqs is not None:
-                for q in reqs:
-                    q.wait()
-        for h in range(1, H + 1):                        # fixed order: bit-reproducible
-            self.acc[:, : self.n_loc] += self.back[h - 1][:, : self.n_loc]
-            if with_potential:
-                self.phi[: self.n_loc] += self.back_phi[h - 1][: self.n_loc]
-        if self.split_half:                              # what the rank half-way round worked out for this one
-            lo = self.n_loc // 2 if r < (r + P // 2) % P else 0        # the lower rank did its own lower half itself
-            k = self.n_loc - lo
-            self.acc[:, lo: self.n_loc] += self.back[H][:, :k]
-            if with_potential:
-                self.phi[lo: self.n_loc] += self.back_phi[H][:k]
+                wait_back(reqs)
+
+        def closing():
+            for h in range(1, H + 1):                    # fixed order: bit-reproducible
+                self.acc[:, : self.n_loc] += self.back[h - 1][:, : self.n_loc]
+                if with_potential:
+                    self.phi[: self.n_loc] += self.back_phi[h - 1][: self.n_loc]
+            if self.split_half:                          # what the rank half-way round worked out for this one
+                lo = self.n_loc // 2 if r < (r + P // 2) % P else 0        # the lower rank did its own lower half itself
+                k = self.n_loc - lo
+                self.acc[:, lo: self.n_loc] += self.back[H][:, :k]
+                if with_potential:
+                    self.phi[lo: self.n_loc] += self.back_phi[H][:k]
+        if hp is not None:
+            hp.closing(closing)
+        else:
+            closing()
 
     def accel(self, eps: float, G: float = 1.0, with_potential: bool = False) -> None:
         """acc <- a(x) of the owned sinks due to ALL particles; with_potential also accumulates self.phi over the chunks."""

@@ -15,11 +15,22 @@ region. One "step" is one kick-drift-kick step = one all-pairs force evaluation 
 the O(N) kick/drift kernels and, for N > 1 GPUs, the ring exchange of source chunks (sink decomposition, strong
 scaling: the total problem is fixed, every rank owns N/P sinks).
 
+N > 1 times BOTH schedules of the sharded force evaluation (bachelor_thesis_n_body_amd/dist.py) in the one invocation, W warm-up +
+exactly K timed steps each, on the same ranks and state: first the one-sided ring SURVEY.md §8(e) names (P-1 position hops, no
+accelerations travel), then the pair-symmetric schedule (P//2 hops, partial sums returned). The contract's keys (`value`,
+`ms_per_step`, `ring`, `roofline.*`) are the FASTER one's and say which (`roofline.schedule`); `roofline.one_sided` and
+`roofline.pair_symmetric` hold both (ms_per_step, kernel_ms_per_step, ring incl. the return leg's back_comm_ms / back_exposed_ms /
+add_ms). `--schedule` restricts the run to one of them. Every rank runs a stall watchdog (NB_BENCH_STALL_S, default 120 s without a
+progress mark): if a schedule stops advancing after another one completed, rank 0 still prints the line for the completed one with
+`roofline.stalled` naming where the other stopped, and the ranks exit; a self-launched run is also supervised by the parent
+(per-rank heartbeat files; all ranks killed by PID and exit code 4 if none advances).
+
 Rank 0 prints ONE JSON line. Besides the contract's keys it carries
-  roofline     — the dominant kernel (accel_f32_kernel) against the gfx950 vector-FP32 peak, at the conventional
+  roofline     — the dominant kernel (accel_sym_f32_kernel) against the gfx950 vector-FP32 peak, at the conventional
                  20 flop per interaction; durations from HIP events on the launch stream
   cpu_baseline — the C oracle (oracle/nbody_oracle.c, OpenMP, fp64) timed on this host on a bounded sample of the
-                 same workload (the first M sinks against all N sources), rank 0 / 1 GPU only.
+                 same workload (the first M sinks against all N sources), rank 0 / 1 GPU only; `numpy`: the NumPy oracle at
+                 N = 16 384 (SURVEY.md §8d leg (i)); `host`: CPU model, logical CPUs, threads used.
 """
 from __future__ import annotations
 
@@ -141,8 +152,51 @@ class KernelTimer:
         return (sum(ms) / len(ms), sum(inter) / len(inter), len(ms)) if ms else (0.0, 0.0, 0)
 
 
-def cpu_baseline(state, eps, budget_s=12.0):
-    """C oracle, fp64, OpenMP over sinks: first M sinks of the workload against all N sources."""
+def host_identity(omp_threads=None):
+    """The host the CPU legs ran on: logical CPUs, what this process may use, the model string, and the OpenMP thread count of the C leg."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return {"cpu_count": os.cpu_count(), "cpus_available_to_this_process": avail, "model": model, "omp_threads": omp_threads,
+            "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS")}
+
+
+def cpu_baseline_numpy(state, eps, n_src=16384, budget_s=8.0):
+    """SURVEY.md §8(d) leg (i): the NumPy fp64 oracle (oracle/nbody_oracle.py: chunked einsum, whatever threads NumPy's BLAS-free
+    kernels use = 1) on the first `n_src` particles of the workload; interactions/s of an O(N^2) kernel does not depend on N, so a
+    bounded number of sinks is timed (about `budget_s` seconds) and the sample says so."""
+    try:
+        from oracle import nbody_oracle as ora
+    except ImportError:
+        return None
+    n_src = min(n_src, state.n)
+    pos = np.ascontiguousarray(state.pos[:n_src], dtype=np.float64)
+    mass = np.ascontiguousarray(state.mass[:n_src], dtype=np.float64)
+    probe = min(256, n_src)
+    t0 = time.perf_counter()
+    ora.compute_forces(pos, mass, eps, sinks=pos[:probe])
+    rate = probe * n_src / max(time.perf_counter() - t0, 1e-9)
+    m_snk = int(min(n_src, max(probe, budget_s * rate / n_src)))
+    t0 = time.perf_counter()
+    ora.compute_forces(pos, mass, eps, sinks=pos[:m_snk])
+    t = time.perf_counter() - t0
+    return {"value": m_snk * n_src / t, "unit": "interactions/s", "cores": 1, "kind": "port",
+            "sample": f"NumPy oracle fp64 (oracle/nbody_oracle.py): first {m_snk} sinks x first {n_src} sources of the same Plummer workload, {t:.1f} s"}
+
+
+def cpu_baseline(state, eps, budget_s=12.0, numpy_budget_s=8.0):
+    """C oracle, fp64, OpenMP over sinks: first M sinks of the workload against all N sources (SURVEY.md §8(d) leg (ii): the host C build
+    of the same kernel on the cores one GPU's share of the host has). `numpy`: leg (i), the NumPy oracle at N = 16 384. `host`: which
+    machine that was."""
     so = ROOT / "oracle" / "libnbody_oracle.so"
     if not so.exists():
         return None
@@ -173,40 +227,156 @@ def cpu_baseline(state, eps, budget_s=12.0):
     rate = probe * n / t
     m_snk = int(min(n, max(probe, (budget_s * rate / n) // threads * threads)))
     t = run(m_snk)
-    return {"value": m_snk * n / t, "unit": "interactions/s", "cores": threads, "kind": "port",
-            "sample": f"C oracle fp64 OpenMP: first {m_snk} sinks x all {n} sources of the same Plummer workload, {t:.1f} s"}
+    out = {"value": m_snk * n / t, "unit": "interactions/s", "cores": threads, "kind": "port",
+           "sample": f"C oracle fp64 OpenMP: first {m_snk} sinks x all {n} sources of the same Plummer workload, {t:.1f} s",
+           "host": host_identity(threads)}
+    if numpy_budget_s and numpy_budget_s > 0:
+        out["numpy"] = cpu_baseline_numpy(state, eps, budget_s=numpy_budget_s)
+    return out
 
 
-def self_launch(args) -> int:
-    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (never an exec; nothing in THIS
-    process has imported torch or touched the GPU) with the environment torch.distributed.run would give them (RANK,
-    LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT), let rank 0's JSON line through on stdout and return
-    non-zero if any rank failed (the surviving ranks are then terminated by PID, not left waiting in a collective)."""
-    import socket
-    import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver
-        env.setdefault("OMP_NUM_THREADS", "1")
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+class Heartbeat:
+    """Progress marks of one rank. Every call stamps the in-process clock (read by the rank's own `StallWatchdog` thread) — two
+    assignments, nothing else on the timed path. When the parent of a self-launched run asked for it (NB_BENCH_HEARTBEAT_DIR) a daemon
+    thread rewrites a small per-rank file with the label of the latest mark whenever it has changed (every `flush_s` seconds), whose
+    modification time and content the parent watches."""
+
+    def __init__(self, rank, directory=None, flush_s=0.2):
+        self.rank, self.label, self.t = rank, "start", time.monotonic()
+        directory = directory if directory is not None else os.environ.get("NB_BENCH_HEARTBEAT_DIR")
+        self.path = os.path.join(directory, "rank%d" % rank) if directory else None
+        if self.path:
+            import threading
+            self._write("start")
+            threading.Thread(target=self._flush, args=(flush_s,), name="nb-bench-heartbeat", daemon=True).start()
+
+    def __call__(self, label):
+        self.label, self.t = label, time.monotonic()
+
+    def _write(self, label):
+        try:
+            with open(self.path, "w") as f:
+                f.write(label + "\n")
+        except OSError:
+            pass
+
+    def _flush(self, every):
+        written = "start"
+        while True:
+            time.sleep(every)
+            label = self.label
+            if label != written:
+                self._write(label)
+                written = label
+
+
+class StallWatchdog:
+    """A daemon thread beside the rank's main thread: when the heartbeat has not moved for `stall_s` seconds (a collective every rank is
+    alive in but none leaves: a schedule bug, not a crash) it calls `on_stall(label)` — which reports what was measured before the stall —
+    and ends the process with the code that returns (os._exit: the main thread sits in a device synchronise that will never return)."""
+
+    def __init__(self, heartbeat, stall_s, on_stall):
+        import threading
+        self.hb, self.stall_s, self.on_stall = heartbeat, float(stall_s), on_stall
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, name="nb-bench-watchdog", daemon=True)
+        self._th.start()
+
+    def _run(self):
+        while not self._stop.wait(min(1.0, self.stall_s / 4.0)):
+            if time.monotonic() - self.hb.t > self.stall_s:
+                code = 3
+                try:
+                    code = int(self.on_stall(self.hb.label))
+                finally:
+                    sys.stdout.flush()
+                    sys.stderr.flush()
+                    os._exit(code)
+
+    def stop(self):
+        self._stop.set()
+
+
+def supervise(procs, heartbeat_dir, stall_s, poll_s=0.05):
+    """Wait for the rank processes `procs` (subprocess.Popen). Returns the exit code of the command: 0 when every rank returned 0; the first
+    failing rank's code otherwise (the surviving ranks are then terminated by PID, not left waiting in a collective); 4 when no rank's
+    heartbeat file advanced for `stall_s` seconds although all are alive — an all-alive deadlock: every rank is killed (by PID; these are
+    this process' own children) and the last mark each one reached is printed on stderr."""
     rc, live = 0, list(procs)
+    last_change, seen = time.monotonic(), {}
     while live:
         for p in list(live):
             code = p.poll()
             if code is None:
                 continue
             live.remove(p)
+            last_change = time.monotonic()
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 1
                 for q in live:                                  # a dead rank leaves the others stuck in a collective
                     q.terminate()
-        time.sleep(0.05)
+        if heartbeat_dir and stall_s and live:
+            for r in range(len(procs)):
+                try:
+                    m = os.stat(os.path.join(heartbeat_dir, "rank%d" % r)).st_mtime_ns
+                except OSError:
+                    continue
+                if seen.get(r) != m:
+                    seen[r], last_change = m, time.monotonic()
+            if time.monotonic() - last_change > stall_s:
+                marks = []
+                for r in range(len(procs)):
+                    try:
+                        marks.append("rank %d: %s" % (r, open(os.path.join(heartbeat_dir, "rank%d" % r)).read().strip()))
+                    except OSError:
+                        marks.append("rank %d: no heartbeat" % r)
+                print("bench.py: no rank advanced for %.0f s — killing all ranks. Last marks: %s" % (stall_s, "; ".join(marks)), file=sys.stderr, flush=True)
+                for q in live:
+                    q.kill()
+                for q in live:
+                    q.wait()
+                return rc or 4
+        time.sleep(poll_s)
     return rc
+
+
+def stall_seconds():
+    """Seconds without progress after which a multi-rank run is declared stalled (NB_BENCH_STALL_S; default 120: RCCL's first connection
+    set-up and the generation of the workload are slow, a step is milliseconds)."""
+    try:
+        return max(1.0, float(os.environ.get("NB_BENCH_STALL_S", "120")))
+    except ValueError:
+        return 120.0
+
+
+def self_launch(args, argv=None, child=None) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (never an exec; nothing in THIS
+    process has imported torch or touched the GPU) with the environment torch.distributed.run would give them (RANK,
+    LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT), let rank 0's JSON line through on stdout and return
+    non-zero if any rank failed or — `supervise` — if all ranks are alive but none advances (each rank also runs its own
+    StallWatchdog, which fires first and still reports what it had measured; the parent's limit is 30 s longer)."""
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    hb_dir = tempfile.mkdtemp(prefix="nb_bench_hb_")
+    procs = []
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NB_BENCH_HEARTBEAT_DIR=hb_dir)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver
+            env.setdefault("OMP_NUM_THREADS", "1")
+            procs.append(subprocess.Popen([sys.executable, child or str(Path(__file__).resolve())] + (sys.argv[1:] if argv is None else list(argv)), env=env))
+        return supervise(procs, hb_dir, stall_seconds() + float(os.environ.get("NB_BENCH_PARENT_MARGIN_S", "30")))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(hb_dir, ignore_errors=True)
 
 
 def single_process(args) -> int:
@@ -273,6 +443,11 @@ def main():
                          "source blocks, no torch.distributed); with --same-device all N shards sit on GPU 0 (rehearsal)")
     ap.add_argument("--one-sided-schedule", action="store_true",
                     help="N > 1: every rank sums all N chunks one-sidedly for its own sinks (rounds 1-2) instead of the pair-symmetric schedule (A/B)")
+    ap.add_argument("--schedule", choices=["both", "pair-symmetric", "one-sided"], default="both",
+                    help="N > 1: which schedule(s) of the force evaluation to time (dist.py). 'both' (default): the one-sided ring, then the "
+                         "pair-symmetric schedule, on the same ranks and state — the line's contract keys are the faster one's, roofline.one_sided / "
+                         ".pair_symmetric hold both")
+    ap.add_argument("--inject-stall", default=None, help=argparse.SUPPRESS)      # test hook: <rank>:<region>:<step>
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="do not run the sustained-clock probe beside the timed region (for runs under rocprofv3 --pmc, which serialises kernels)")
@@ -306,24 +481,56 @@ def main():
         raise SystemExit(f"rank {rank}: no device cuda:{local_rank} ({torch.cuda.device_count()} visible); use --same-device --backend gloo to rehearse on one GPU")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+
+    # ---- progress marks and the stall watchdog (N > 1 only: a deadlocked collective would otherwise sit until the caller's time limit) ----
+    hb = Heartbeat(rank) if world > 1 else (lambda *a, **k: None)
+    done = {}                      # schedule name -> measured region (filled as regions complete; read by the watchdog)
+    emit = {"fn": None}            # set once the JSON builder exists
+
+    def on_stall(label):
+        # every rank completed the same regions (they end with a barrier + all-reduce), so every rank takes the same exit code
+        if done and emit["fn"] is not None:
+            if rank == 0:
+                print(f"bench.py: rank 0 made no progress for {stall_seconds():.0f} s at '{label}': reporting the region(s) that completed", file=sys.stderr, flush=True)
+                emit["fn"](stalled_at=label)
+            else:
+                time.sleep(5.0)    # rank 0 prints first
+            return 0
+        print(f"bench.py: rank {rank} made no progress for {stall_seconds():.0f} s at '{label}' and no region had completed", file=sys.stderr, flush=True)
+        return 3
+    watchdog = StallWatchdog(hb, stall_seconds(), on_stall) if world > 1 else None
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+    hb("process group up")
 
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
     eps, dt, G = 0.01, 1.0 / 256.0, 1.0
     state = nb.plummer_sphere(args.n, seed=0, dtype=np_dtype)
     if args.general_mass:       # one mass 1 ulp up: same physics to ~1e-7/N, but no longer the equal-mass special case
         state.mass[-1] = np.nextafter(state.mass[-1], np_dtype(1.0))
-    eng = nb.ShardedEngine(args.n, np_dtype, device=device, mode=args.mode, pairwise=False if args.one_sided_schedule else None)
+    hb("workload generated")
+
+    # ---- which schedule(s) of the N-rank force evaluation are timed (dist.py): both by default, the one-sided ring FIRST ----
+    # (it is the schedule SURVEY.md §8(e) names and the simpler message pattern; if the pair-symmetric one then stalled on real links the
+    # run would still report a measured number)
+    schedule = "one-sided" if args.one_sided_schedule else args.schedule
+    if world == 1:
+        plan = [None]
+    elif os.environ.get("NB_PAIRWISE_SCHEDULE", "1") == "0" or schedule == "one-sided":
+        plan = [False]
+    elif schedule == "pair-symmetric":
+        plan = [True]
+    else:
+        plan = [False, True]
+    eng = nb.ShardedEngine(args.n, np_dtype, device=device, mode=args.mode, pairwise=plan[0])
+    eng.heartbeat = hb if world > 1 else None
     eng.set_state(state)
-    timer = KernelTimer(torch)
-    eng.kernel_timer = timer
-    probe = HopProbe(torch, device) if (world > 1 and args.mode == "ring") else None
-    eng.hop_probe = probe
+    hb("state resident")
 
     def sync():
         torch.cuda.synchronize()
@@ -331,44 +538,81 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    eng.accel(eps, G)                      # initial a(x): not part of a step
-    for _ in range(args.warmup):
-        eng.step(dt, 1, eps, G)
-    sync()
-    # sustained shader clock of this rank's GPU over the timed region (one sleeping wave on a private stream, nb_clock_probe_*; its window is
-    # ended by a word written on the compute stream behind the last step, so the synchronisation below never waits for it):
-    # boxes differ by several per cent in the clock they hold under this kernel; cycles per interaction is the box-independent figure
-    clock = None if args.no_clock_probe else nb.ClockProbe(local_rank, 5000.0)
-    timer.enabled = True
-    if probe is not None:
-        probe.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step(dt, 1, eps, G)
-    if clock is not None:
-        clock.stop(torch.cuda.current_stream().cuda_stream)
-    sync()
-    elapsed = time.perf_counter() - t0
-    timer.enabled = False
-    if probe is not None:
-        probe.enabled = False
-    clock_mhz, clock_ms = clock.end() if clock is not None else (None, None)
-    clock_min = clock_mhz
-    if world > 1:
-        t = torch.tensor([elapsed, -(clock_mhz or 0.0)], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0].item())
-        clock_min = -float(t[1].item()) if clock_mhz else None
+    inject = None
+    if args.inject_stall:          # test hook: "<rank>:<region index>:<step>" — that rank stops taking part there (tests/test_gpu_bench_contract.py)
+        inject = tuple(int(v) for v in args.inject_stall.split(":"))
 
-    symmetric = eng.k.last_accel_symmetric() if world == 1 else eng.own_chunk_symmetric
-    sym_all = symmetric and (world == 1 or eng.pairwise)       # N ranks: the pair-symmetric schedule makes every hop two-sided
-    interactions = float(args.n) * float(args.n) * args.steps
-    value = interactions / elapsed
-    k_ms, k_inter, k_count = timer.summary()
+    def timed_region(idx, pairwise):
+        name = "single" if pairwise is None else ("pair-symmetric" if pairwise else "one-sided")
+        if pairwise is not None:
+            eng.set_schedule(pairwise)
+        timer = KernelTimer(torch)
+        eng.kernel_timer = timer
+        probe = HopProbe(torch, device) if (world > 1 and args.mode == "ring") else None
+        eng.hop_probe = probe
+        eng.accel(eps, G)                      # initial a(x): not part of a step
+        for w in range(args.warmup):
+            eng.step(dt, 1, eps, G)
+            hb(f"{name}: warm-up step {w + 1}")
+        sync()
+        hb(f"{name}: warm-up done")
+        # sustained shader clock of this rank's GPU over the timed region (one sleeping wave on a private stream, nb_clock_probe_*; its window is
+        # ended by a word written on the compute stream behind the last step, so the synchronisation below never waits for it):
+        # boxes differ by several per cent in the clock they hold under this kernel; cycles per interaction is the box-independent figure
+        clock = None if args.no_clock_probe else nb.ClockProbe(local_rank, 5000.0)
+        timer.enabled = True
+        if probe is not None:
+            probe.enabled = True
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            if inject is not None and inject == (rank, idx, k):
+                time.sleep(1e6)
+            eng.step(dt, 1, eps, G)
+            hb(f"{name}: step {k + 1} of {args.steps} enqueued")
+        if clock is not None:
+            clock.stop(torch.cuda.current_stream().cuda_stream)
+        sync()
+        elapsed = time.perf_counter() - t0
+        hb(f"{name}: timed region synchronised")
+        timer.enabled = False
+        if probe is not None:
+            probe.enabled = False
+        clock_mhz, clock_ms = clock.end() if clock is not None else (None, None)
+        clock_min = clock_mhz
+        if world > 1:
+            t = torch.tensor([elapsed, -(clock_mhz or 0.0)], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0].item())
+            clock_min = -float(t[1].item()) if clock_mhz else None
+        symmetric = eng.k.last_accel_symmetric() if world == 1 else eng.own_chunk_symmetric
+        k_ms, k_inter, k_count = timer.summary()
+        reg = {"name": name, "pairwise": bool(eng.pairwise), "elapsed": elapsed, "symmetric": bool(symmetric),
+               "sym_all": bool(symmetric and (world == 1 or eng.pairwise)),      # N ranks: the pair-symmetric schedule makes every hop two-sided
+               "k_ms": k_ms, "k_inter": k_inter, "k_count": k_count, "ring": probe.summary() if probe is not None else None,
+               "clock_mhz": clock_mhz, "clock_ms": clock_ms, "clock_min": clock_min}
+        hb(f"{name}: region complete")
+        return reg
+
     peak = PEAK_FP32_VECTOR_TFLOPS if args.dtype == "f32" else PEAK_FP64_VECTOR_TFLOPS
-    achieved = k_inter * FLOP_PER_INTERACTION / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    interactions = float(args.n) * float(args.n) * args.steps
 
-    if rank == 0:
+    def brief(reg):
+        """One schedule's timed region in the A/B block of the line."""
+        ach = reg["k_inter"] * FLOP_PER_INTERACTION / (reg["k_ms"] * 1e-3) / 1e12 if reg["k_ms"] > 0 else 0.0
+        return {"ms_per_step": reg["elapsed"] / args.steps * 1e3, "value": interactions / reg["elapsed"],
+                "kernel_ms_per_step": reg["k_ms"] * reg["k_count"] / max(1, args.steps), "launches_timed": reg["k_count"],
+                "avg_launch_ms": reg["k_ms"], "interactions_per_launch": reg["k_inter"], "frac": ach / peak,
+                "sustained_clock_mhz": reg["clock_mhz"], "ring": reg["ring"]}
+
+    def emit_line(stalled_at=None):
+        """Rank 0's ONE JSON line from the regions completed so far: the contract's keys describe the FASTER schedule timed in this run."""
+        regs = dict(done)
+        best = min(regs.values(), key=lambda g: g["elapsed"])
+        elapsed, symmetric, sym_all = best["elapsed"], best["symmetric"], best["sym_all"]
+        k_ms, k_inter, k_count = best["k_ms"], best["k_inter"], best["k_count"]
+        clock_mhz, clock_ms, clock_min = best["clock_mhz"], best["clock_ms"], best["clock_min"]
+        value = interactions / elapsed
+        achieved = k_inter * FLOP_PER_INTERACTION / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         out = {
             "metric": "particle-pair interactions/s",
             "value": value,
@@ -385,14 +629,14 @@ def main():
             "config": {"workload": f"plummer_sphere N={args.n} {args.dtype} eps=0.01 dt=1/256, KDK step = 1 all-pairs force evaluation",
                        "n": args.n, "parallelism": f"sink-decomposition x{world}, {args.mode} exchange of source chunks" + (
                            f" ({world // 2} of {world - 1} hops: each pair of chunks is worked on by one of its owners, partial sums returned point to point)"
-                           if (world > 1 and eng.pairwise) else ""),
+                           if (world > 1 and best["pairwise"]) else ""),
                        "masses": "general (one mass perturbed by 1 ulp)" if args.general_mass else "equal"},
             "world_size": world,
             "backend": (args.backend if args.backend == "gloo" else "nccl (RCCL)") if world > 1 else None,
             "same_device": bool(args.same_device) if world > 1 else None,
             # rank 0's ring hops inside the timed region: exchange time vs the kernel it was posted beside, and what of it the
-            # compute stream still had to wait for (0 = hidden)
-            "ring": probe.summary() if probe is not None else None,
+            # compute stream still had to wait for (0 = hidden); pair-symmetric schedule: the return leg too (back_*, add_ms)
+            "ring": best["ring"],
             "roofline": {"bound": "vector_" + ("fp32" if args.dtype == "f32" else "fp64"),
                          "kernel": ("accel_sym_%s_kernel" if sym_all else "accel_%s_kernel") % args.dtype,
                          "variant": "uniform_mass" if eng.uniform_mass else "general",
@@ -404,7 +648,7 @@ def main():
                          # (3 sub, 3 fma, rsqrt, 2 mul, 6 fma) = 12 flop per delivered interaction instead of the convention's 20
                          "pair_symmetry": bool(symmetric),
                          "pair_symmetry_scope": (None if not symmetric else "every launch" if sym_all else "own-chunk launch of each rank only"),
-                         "schedule": (None if world == 1 else "pair-symmetric: each pair of chunks worked on by one owner, partial sums returned" if eng.pairwise else "one-sided: every rank sums all chunks for its own sinks"),
+                         "schedule": (None if world == 1 else "pair-symmetric: each pair of chunks worked on by one owner, partial sums returned" if best["pairwise"] else "one-sided: every rank sums all chunks for its own sinks"),
                          "pair_terms_evaluated_per_launch_approx": (k_inter / 2.0 if sym_all else k_inter),   # PMC count (one v_rsq per term): profiles/r03_*_rocprofv3_summary.txt
                          "executed_flop_per_interaction": EXECUTED_FLOP_SYM if sym_all else EXECUTED_FLOP_ONE_SIDED,
                          "frac_executed_flops": achieved / peak * (EXECUTED_FLOP_SYM if sym_all else EXECUTED_FLOP_ONE_SIDED) / FLOP_PER_INTERACTION,
@@ -415,6 +659,16 @@ def main():
                          "traffic_source": "NOT measured in this run: HBM bytes per launch from the rocprofv3 --pmc passes of this same command committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE: the partial-sum slabs of the pair-symmetric kernel); algorithmic bytes = 28*N"},
         }
         r = out["roofline"]
+        if world > 1:
+            # the A/B of the two N-rank schedules, each timed for `steps` steps in THIS run on the same ranks and state; the contract's keys
+            # above are the faster one's (`schedule`). `stalled`: a schedule that stopped advancing (the watchdog then printed this line)
+            r["schedule_selection"] = "faster of the schedules timed in this run (each: warm-up steps, then exactly `steps` timed steps)"
+            r["one_sided"] = brief(regs["one-sided"]) if "one-sided" in regs else None
+            r["pair_symmetric"] = brief(regs["pair-symmetric"]) if "pair-symmetric" in regs else None
+            if stalled_at is not None:
+                r["stalled"] = {"at": stalled_at, "no_progress_for_s": stall_seconds(),
+                                "schedules_not_completed": [("pair-symmetric" if pw else "one-sided") for pw in plan
+                                                            if ("pair-symmetric" if pw else "one-sided") not in regs]}
         if clock_mhz:
             simds = 256 * 4
             r["sustained_clock_mhz"] = clock_mhz
@@ -439,6 +693,24 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(state, eps)
         print(json.dumps(out), flush=True)
+
+    emit["fn"] = emit_line
+    for idx, pairwise in enumerate(plan):
+        try:
+            reg = timed_region(idx, pairwise)
+        except Exception as e:     # a schedule that FAILS after another completed: report what was measured (the other ranks' watchdogs do the same)
+            if not done:
+                raise
+            print(f"bench.py: rank {rank}: schedule {idx} failed: {e!r}", file=sys.stderr, flush=True)
+            if rank == 0:
+                emit_line(stalled_at=f"exception: {e!r}")
+            sys.stdout.flush()
+            os._exit(0)            # no destroy_process_group: the peers may be stuck in the failed exchange
+        done[reg["name"]] = reg
+    if watchdog is not None:
+        watchdog.stop()
+    if rank == 0:
+        emit_line()
     if world > 1:
         dist.destroy_process_group()
 

@@ -45,6 +45,10 @@ def _worker(rank, world, port, n, mode, pairwise, out_dir):
             ps = probe.summary()
             # position hops: all P - 1 other chunks one-sidedly, or P // 2 with the pair-symmetric schedule (the other chunks' owners do the work)
             assert ps["hops_timed"] == (world // 2 if pairwise else world - 1) and ps["comm_ms"] >= 0.0
+            if pairwise:     # the return leg: one partial per two-sided hop ((P - 1) // 2, + the split half-way hop of an even ring) and the closing adds
+                assert ps["returns_timed"] == world // 2 and ps["evaluations_timed"] == 1 and ps["back_comm_ms"] >= 0 and ps["add_ms"] >= 0
+            else:
+                assert "back_comm_ms" not in ps
         else:
             assert probe.summary() is None
         acc0 = eng.gather_state().acc
@@ -107,3 +111,49 @@ def test_single_rank_engine_without_process_group():
     np.testing.assert_allclose(eng.gather_state().pos, o.pos, rtol=1e-13, atol=1e-15)
     with pytest.raises(RuntimeError, match="HIP device"):
         nb.ShardedEngine(40, np.float64, device="cpu")          # no silent CPU path in the product
+
+
+def _switch_worker(rank, world, port, n, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bachelor_thesis_n_body_amd as nb
+        from cpu_kernels import OracleKernels
+        s = nb.plummer_sphere(n, 9)
+        # the ranks DISAGREE on the flag (as with NB_PAIRWISE_SCHEDULE exported on some nodes only): the engine takes the MIN over the group
+        eng = nb.ShardedEngine(n, np.float64, device="cpu", kernels=OracleKernels(), pairwise=(rank != 1))
+        assert eng.pairwise is False and eng.H == 0
+        eng.set_state(s)
+        beats = []
+        eng.heartbeat = beats.append
+        eng.accel(0.02)
+        a_one = eng.gather_state().acc
+        eng.set_schedule(True)                      # live switch (bench.py's A/B): same state, the other message pattern
+        assert eng.pairwise and eng.H == (world - 1) // 2 and eng.split_half == (world % 2 == 0)
+        eng.accel(0.02)
+        a_pair = eng.gather_state().acc
+        assert len(beats) == world // 2 + 1 and beats[0] == "hop 0"
+        eng.set_schedule(False)
+        eng.step(1 / 128, 2, 0.02)
+        eng.set_schedule(True)
+        eng.step(1 / 128, 2, 0.02)
+        st = eng.gather_state()
+        if rank == 0:
+            np.savez(Path(out_dir) / "res.npz", a_one=a_one, a_pair=a_pair, pos=st.pos)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(3, 70), (4, 90)])
+def test_schedule_flag_agreement_and_live_switch(tmp_path, world, n):
+    from oracle import nbody_oracle as ora
+    import bachelor_thesis_n_body_amd as nb
+    mp.spawn(_switch_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    r = np.load(tmp_path / "res.npz")
+    s = nb.plummer_sphere(n, 9)
+    ref = ora.compute_forces(s.pos, s.mass, 0.02)
+    np.testing.assert_allclose(r["a_one"], ref, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(r["a_pair"], ref, rtol=1e-12, atol=1e-14)
+    o = ora.State(s.pos.copy(), s.vel.copy(), s.mass.copy())
+    ora.step(o, 1 / 128, 4, eps=0.02)
+    np.testing.assert_allclose(r["pos"], o.pos, rtol=1e-12, atol=1e-14)

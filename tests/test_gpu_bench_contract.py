@@ -1,6 +1,7 @@
 """bench.py end to end on the GPU at a reduced size: ONE JSON line with every key of the driver's contract plus the roofline
 and cpu_baseline objects."""
 import json
+import os
 import subprocess
 import sys
 from pathlib import Path
@@ -28,6 +29,9 @@ def test_bench_prints_one_contract_json_line():
     assert r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.2 < r["frac"] < 1.0
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["value"] < j["value"]
+    # both CPU legs and the host they ran on
+    assert c["host"]["cpu_count"] >= c["cores"] == c["host"]["omp_threads"] and isinstance(c["host"]["model"], str)
+    assert c["numpy"]["cores"] == 1 and 0 < c["numpy"]["value"] < c["value"] and "16384 sources" in c["numpy"]["sample"]
     assert r["variant"] == "uniform_mass" and j["world_size"] == 1 and j["ring"] is None
     # HBM traffic measured live (two rocprofv3 --pmc child passes of the same command), not read from a committed file
     assert r["traffic_source"].startswith("measured in this run"), r["traffic_source"]
@@ -67,6 +71,41 @@ def test_bench_two_ranks_self_launched_on_one_gpu(dtype):
     assert r["launches_timed"] == 6 and r["interactions_per_launch"] == 32768.0 ** 2 and 0.05 < r["frac"] < 1.0
     assert "cpu_baseline" not in j          # rank 0 at N = 1 only
     assert 1200.0 < r["sustained_clock_mhz_min_over_ranks"] <= r["sustained_clock_mhz"] * 1.2
+    # BOTH schedules were timed in the one invocation (3 steps each); the contract keys are the faster one's
+    one, pair = r["one_sided"], r["pair_symmetric"]
+    for blk in (one, pair):
+        assert blk["launches_timed"] == 6 and blk["ms_per_step"] > 0 and blk["kernel_ms_per_step"] > 0 and blk["ring"]["hops_timed"] == 3
+        assert blk["value"] == pytest.approx(65536 ** 2 * 3 / (blk["ms_per_step"] * 3e-3), rel=1e-6)
+    assert j["ms_per_step"] == pytest.approx(min(one["ms_per_step"], pair["ms_per_step"]))
+    assert ("pair-symmetric" in r["schedule"]) == (pair["ms_per_step"] <= one["ms_per_step"]) and "stalled" not in r
+    # the return leg of the pair-symmetric schedule is visible: one partial per step (the split half-way hop of the 2-ring), waits, closing adds
+    pr = pair["ring"]
+    assert pr["returns_timed"] == 3 and pr["evaluations_timed"] == 3 and pr["back_comm_ms"] > 0 and pr["back_exposed_ms"] >= 0 and pr["add_ms"] > 0
+    assert "back_comm_ms" not in one["ring"]
+
+
+def test_bench_reports_the_completed_schedule_when_the_other_stalls():
+    """All ranks alive, rank 1 stops taking part in the SECOND schedule's timed region (injected): each rank's watchdog fires after
+    NB_BENCH_STALL_S, rank 0 prints the line of the schedule that completed — labelled — and the command returns 0."""
+    env = dict(os.environ, NB_BENCH_STALL_S="15", NB_BENCH_PARENT_MARGIN_S="60")
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "32768",
+                          "--backend", "gloo", "--same-device", "--inject-stall", "1:1:1"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.stderr[-3000:], out.stdout[-1000:])
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    r = j["roofline"]
+    assert r["one_sided"] is not None and r["pair_symmetric"] is None and "one-sided" in r["schedule"]
+    assert r["stalled"]["schedules_not_completed"] == ["pair-symmetric"] and "pair-symmetric" in r["stalled"]["at"]
+    assert j["ms_per_step"] == pytest.approx(r["one_sided"]["ms_per_step"]) and j["value"] > 0
+
+
+def test_bench_single_schedule_switch():
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n", "32768",
+                          "--backend", "gloo", "--same-device", "--schedule", "pair-symmetric"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stderr[-3000:], out.stdout[-1000:])
+    r = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])["roofline"]
+    assert r["one_sided"] is None and r["pair_symmetric"]["launches_timed"] == 4 and "pair-symmetric" in r["schedule"]
 
 
 def test_bench_propagates_a_failing_rank():

@@ -1,4 +1,4 @@
-"""Rank 0's share of the multi-GPU headline run, with the REAL RCCL transport, on one GPU: `ShardedEngine(virtual_world=P)` — the one real rank plays
+"""Rank 0's share of the multi-GPU headline run, with the REAL RCCL transport, on one GPU: `tools.virtual_ring.VirtualRingEngine` — the one real rank plays
 rank 0 of a P-rank ring and passes the other ranks' source blocks through the communicator to itself (tests/test_gpu_rccl.py). Prints, for P = 1, 2, 4, 8 at
 N = 2^20 fp32 (BASELINE configs[2] shapes): time per force evaluation of rank 0's N/P sinks against all N sources, per-hop exchange time, the kernel it overlaps
 and the part of the exchange the compute stream had to wait for. What this cannot show is the xGMI link itself (a self send is a device-local copy).
@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bachelor_thesis_n_body_amd as nb
 from bachelor_thesis_n_body_amd.dist import HopProbe
+from tools.virtual_ring import VirtualRingEngine
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 dtype = np.float64 if (len(sys.argv) > 2 and sys.argv[2] == "f64") else np.float32
@@ -44,7 +45,7 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=
 print(json.dumps({"communicator_stream_high_priority": hp}), flush=True)
 s = nb.plummer_sphere(n, 0, dtype)
 for P in (1, 2, 4, 8):
-    eng = nb.ShardedEngine(n, dtype, device=dev, virtual_world=P if P > 1 else 0, pairwise=pairwise if P > 1 else None)
+    eng = VirtualRingEngine(n, dtype, device=dev, virtual_world=P, pairwise=pairwise) if P > 1 else nb.ShardedEngine(n, dtype, device=dev)
     eng.set_state(s)
     probe = HopProbe(torch, dev); eng.hop_probe = probe
     tm = Timer(); eng.kernel_timer = tm
