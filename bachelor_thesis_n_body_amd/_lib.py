@@ -19,7 +19,8 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libnbody_amd.so"
 
 # NB_OPT_* of include/nbody_amd.h (nb_set_option): the pair-symmetric all-pairs kernels
-OPTIONS = {"pair_symmetry": 1, "sym_min_n": 2, "sym_slab_bytes": 3}
+OPTIONS = {"pair_symmetry": 1, "sym_min_n": 2, "sym_slab_bytes": 3, "sym_scratch_limit": 4}
+QUERIES = {"multi_schedule": 100, "own_chunk_symmetric": 101}
 
 # every symbol include/nbody_amd.h declares: (name, restype, argtypes)
 _vp, _i64, _dbl, _int = C.c_void_p, C.c_int64, C.c_double, C.c_int
@@ -42,6 +43,7 @@ SIGNATURES = {
     "nb_last_run_used_graph": (_int, [_vp]),
     "nb_set_option": (_int, [_vp, _int, _i64]),
     "nb_last_accel_symmetric": (_int, [_vp]),
+    "nb_get_option": (_int, [_vp, _int, C.POINTER(_i64)]),
     "nb_clock_probe_begin": (_int, [_int, _dbl, C.POINTER(_vp)]),
     "nb_clock_probe_stop": (_int, [_vp, _vp]),
     "nb_clock_probe_end": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_dbl)]),

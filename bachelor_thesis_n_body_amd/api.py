@@ -111,8 +111,17 @@ class Engine:
         _lib.check(self._ctx, self._lib.nb_set_option(self._ctx, _lib.OPTIONS[name], int(value)), "nb_set_option")
 
     def last_accel_symmetric(self) -> bool:
-        """True if the last direct-summation force evaluation ran the pair-symmetric kernel (every unordered pair once)."""
+        """True if the last direct-summation force evaluation ran the pair-symmetric kernel (every unordered pair once); a multi-device
+        engine answers for the own-chunk launch of its first device."""
         return bool(self._lib.nb_last_accel_symmetric(self._ctx))
+
+    def get_option(self, name: str) -> int:
+        """nb_get_option: an option as set (-1 = default in force) or a read-only query — 'multi_schedule' (1 = this multi-device engine
+        runs the pair-symmetric schedule), 'own_chunk_symmetric'."""
+        v = C.c_int64()
+        code = _lib.OPTIONS.get(name, _lib.QUERIES.get(name))
+        _lib.check(self._ctx, self._lib.nb_get_option(self._ctx, code, C.byref(v)), "nb_get_option")
+        return int(v.value)
 
     def set_stream(self, hip_stream: int) -> None:
         _lib.check(self._ctx, self._lib.nb_set_stream(self._ctx, C.c_void_p(hip_stream)), "nb_set_stream")

@@ -223,19 +223,26 @@ int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const 
   const int H = (nsets - 1) / 2;
   const int n_o = H + 1 + (nsets % 2 == 0 ? 1 : 0);
   const size_t slot_bytes = NC * n_pad * sizeof(double);
-  int slots_per_pass = (int)std::max<long long>(1, budget / (long long)slot_bytes);
-  if (slots_per_pass > H) slots_per_pass = H > 0 ? H : 1;
-  const int npass = H > 0 ? (H + slots_per_pass - 1) / slots_per_pass : 1;
+  // clamped in 64 bits BEFORE the cast: a budget meant as "unlimited" (INT64_MAX) must not wrap
+  int slots_per_pass = (int)std::min<long long>(std::max<long long>(1, budget / (long long)slot_bytes), (long long)std::max(H, 1));
+  // pass 0 takes o = 0 and the first two-sided offsets, the last pass also the one-sided half offset
   constexpr int QT = SET / TJ;                               // tiles per set
   // groups: ~4096 blocks PER PASS (see accel_f32.hip's split sweep; a pass of a large problem must not shrink to a round or two of blocks)
   int groups_target = env_groups > 0 ? (int)env_groups : (4096 + nsets - 1) / nsets;
   if (groups_target < 1) groups_target = 1;
   const int max_groups_pass = groups_target + 1;
   const size_t part_bytes = (size_t)max_groups_pass * NC * n_pad * sizeof(double);
-  const size_t slab_bytes = (size_t)slots_per_pass * slot_bytes;
-  const size_t tot_bytes = npass > 1 ? NC * (size_t)n * sizeof(double) : 0;
-  int rc = nb_ensure_work(c, part_bytes + slab_bytes + tot_bytes);
-  if (rc) return rc;
+  int npass;
+  size_t slab_bytes, tot_bytes;
+  for (;;) {                                                 // the allocator may refuse the scratch: fewer slots per pass, then give up (one-sided kernel)
+    npass = H > 0 ? (H + slots_per_pass - 1) / slots_per_pass : 1;
+    slab_bytes = (size_t)slots_per_pass * slot_bytes;
+    tot_bytes = npass > 1 ? NC * (size_t)n * sizeof(double) : 0;
+    const int rc = nb_try_ensure_work(c, part_bytes + slab_bytes + tot_bytes, c->sym_scratch_limit);
+    if (rc == NB_OK) break;
+    if (rc != NB_WORK_UNAVAILABLE || slots_per_pass <= 1) return rc;
+    slots_per_pass = (slots_per_pass + 1) / 2;
+  }
   double* part = reinterpret_cast<double*>(c->work);
   double* slab = reinterpret_cast<double*>(reinterpret_cast<char*>(c->work) + part_bytes);
   double* tot = npass > 1 ? reinterpret_cast<double*>(reinterpret_cast<char*>(c->work) + part_bytes + slab_bytes) : nullptr;
@@ -276,17 +283,22 @@ int run_cross(nb_ctx* c, const double* xa, const double* ya, const double* za, c
   const int nsa = (int)((na + SET - 1) / SET), nsb = (int)((nb + SET - 1) / SET);
   const size_t npa = (size_t)nsa * SET, npb = (size_t)nsb * SET;
   const size_t slot_bytes = NC * npb * sizeof(double);
-  int sets_per_pass = (int)std::max<long long>(1, budget / (long long)slot_bytes);
-  if (sets_per_pass > nsa) sets_per_pass = nsa;
+  int sets_per_pass = (int)std::min<long long>(std::max<long long>(1, budget / (long long)slot_bytes), (long long)std::max(nsa, 1));
   constexpr int QT = SET / TJ;
-  int groups = (4096 + sets_per_pass - 1) / sets_per_pass;                  // ~4096 blocks per launch
-  if (groups > nsb * QT) groups = nsb * QT;
-  if (groups < 1) groups = 1;
-  const int tpg = (nsb * QT + groups - 1) / groups;                         // (set of B, tile) pairs per group
-  groups = (nsb * QT + tpg - 1) / tpg;
-  const size_t part_bytes = (size_t)groups * NC * npa * sizeof(double);
-  int rc = nb_ensure_work(c, part_bytes + (size_t)sets_per_pass * slot_bytes);
-  if (rc) return rc;
+  int groups, tpg;
+  size_t part_bytes;
+  for (;;) {                                                 // as run_sym: fewer sets of A per pass if the allocator refuses, then give up
+    groups = (4096 + sets_per_pass - 1) / sets_per_pass;                    // ~4096 blocks per launch
+    if (groups > nsb * QT) groups = nsb * QT;
+    if (groups < 1) groups = 1;
+    tpg = (nsb * QT + groups - 1) / groups;                                 // (set of B, tile) pairs per group
+    groups = (nsb * QT + tpg - 1) / tpg;
+    part_bytes = (size_t)groups * NC * npa * sizeof(double);
+    const int rc = nb_try_ensure_work(c, part_bytes + (size_t)sets_per_pass * slot_bytes, c->sym_scratch_limit);
+    if (rc == NB_OK) break;
+    if (rc != NB_WORK_UNAVAILABLE || sets_per_pass <= 1) return rc;
+    sets_per_pass = (sets_per_pass + 1) / 2;
+  }
   double* part = reinterpret_cast<double*>(c->work);
   double* slab = reinterpret_cast<double*>(reinterpret_cast<char*>(c->work) + part_bytes);
   const bool uniform = (flags & NB_UNIFORM_MASS) != 0;
@@ -342,6 +354,7 @@ int nb_launch_accel_sym_f64(nb_ctx* c, const double* x, const double* y, const d
   const int rc = phi ? (ks == 8 ? NB_RUN(8, true) : ks == 4 ? NB_RUN(4, true) : NB_RUN(2, true))
                      : (ks == 8 ? NB_RUN(8, false) : ks == 4 ? NB_RUN(4, false) : NB_RUN(2, false));
 #undef NB_RUN
+  if (rc == NB_WORK_UNAVAILABLE) return NB_OK;          // no scratch for even one slab slot: *taken stays 0, the caller runs the one-sided kernel
   if (rc) return rc;
   *taken = 1;
   c->last_accel_sym = true;
@@ -367,6 +380,7 @@ int nb_launch_accel_cross_f64(nb_ctx* c, const double* xa, const double* ya, con
   const int rc = pot ? (ks == 8 ? NB_RUN(8, true) : ks == 4 ? NB_RUN(4, true) : NB_RUN(2, true))
                      : (ks == 8 ? NB_RUN(8, false) : ks == 4 ? NB_RUN(4, false) : NB_RUN(2, false));
 #undef NB_RUN
+  if (rc == NB_WORK_UNAVAILABLE) return NB_OK;          // no scratch for even one slab slot: *taken stays 0, the caller runs the one-sided kernel
   if (rc) return rc;
   *taken = 1;
   c->last_accel_sym = true;

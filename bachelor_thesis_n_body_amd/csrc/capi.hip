@@ -29,6 +29,22 @@ int nb_ensure_work(nb_ctx* c, size_t bytes) {
   return NB_OK;
 }
 
+int nb_try_ensure_work(nb_ctx* c, size_t bytes, long long limit) {
+  if (bytes <= c->work_bytes) return NB_OK;
+  if (limit >= 0 && bytes > (size_t)limit) return NB_WORK_UNAVAILABLE;
+  NB_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
+  if (c->work) { NB_HIP(c, hipFree(c->work)); c->work = nullptr; c->work_bytes = 0; }
+  // 25 % headroom so that a slowly growing request does not reallocate every time; the bare request if that is refused
+  for (size_t want : {bytes + bytes / 4, bytes}) {
+    if (limit >= 0 && want > (size_t)limit) continue;
+    if (hipMalloc(&c->work, want) == hipSuccess) { c->work_bytes = want; return NB_OK; }
+    c->work = nullptr;
+    (void)hipGetLastError();                  // out of memory is an answer here, not a sticky error
+  }
+  return NB_WORK_UNAVAILABLE;
+}
+
 static inline size_t esize(int dtype) { return dtype == NB_F64 ? 8 : 4; }
 
 static int use_device(nb_ctx* c) {
@@ -592,6 +608,7 @@ int nb_set_option(nb_ctx* c, int option, int64_t value) {
     case NB_OPT_PAIR_SYMMETRY: c->sym_enable = v; break;
     case NB_OPT_SYM_MIN_N: c->sym_min_n = v; break;
     case NB_OPT_SYM_SLAB_BYTES: c->sym_slab_bytes = v; break;
+    case NB_OPT_SYM_SCRATCH_LIMIT: c->sym_scratch_limit = v; break;
     default: return nb_fail(c, NB_ERR_ARG, "nb_set_option: unknown option");
   }
   if (c->multi) return nb_multi_set_option(c, option, value);
@@ -604,6 +621,20 @@ int nb_last_accel_symmetric(const nb_ctx* c) {
   if (!c) return NB_ERR_ARG;
   if (c->multi) return nb_multi_last_symmetric(c);          // the own-chunk launch of device 0
   return c->last_accel_sym ? 1 : 0;
+}
+
+int nb_get_option(const nb_ctx* c, int option, int64_t* value) {
+  if (!c || !value) return NB_ERR_ARG;
+  switch (option) {
+    case NB_OPT_PAIR_SYMMETRY: *value = c->sym_enable; break;
+    case NB_OPT_SYM_MIN_N: *value = c->sym_min_n; break;
+    case NB_OPT_SYM_SLAB_BYTES: *value = c->sym_slab_bytes; break;
+    case NB_OPT_SYM_SCRATCH_LIMIT: *value = c->sym_scratch_limit; break;
+    case NB_QUERY_MULTI_SCHEDULE: *value = c->multi ? nb_multi_schedule_pairwise(c) : 0; break;
+    case NB_QUERY_OWN_CHUNK_SYMMETRIC: *value = c->multi ? nb_multi_last_symmetric(c) : (c->last_accel_sym ? 1 : 0); break;
+    default: return NB_ERR_ARG;
+  }
+  return NB_OK;
 }
 
 int nb_energy(nb_ctx* c, double eps, double G, double* kinetic, double* potential) {

@@ -51,6 +51,7 @@ struct nb_multi_state {
   std::vector<hipEvent_t> ev_added;                   // [P]
   std::vector<char> added_valid;
   long long pairwise = -1;                            // NB_OPT_PAIR_SYMMETRY of the context (-1: default = on)
+  bool own_chunk_sym = false;                         // device 0's own-chunk launch of the last force evaluation ran the pair-symmetric kernel
   bool uniform = false;
   bool acc_valid = false;
   double acc_eps = -1.0, acc_G = 0.0;
@@ -153,6 +154,7 @@ int refresh_acc_pairwise(nb_ctx* c, double eps, double G, bool with_phi) {
                                    (const double*)src, (const double*)(src + so), (const double*)(src + 2 * so), (const double*)(src + 3 * so), m.cnt[o],
                                    eps * eps, G, (double*)field_ptr(s, 7), (double*)field_ptr(s, 8), (double*)field_ptr(s, 9), flags, phi);
         if (rc) return nb_fail(c, rc, std::string("multi: device ") + std::to_string(m.dev[g]) + ": " + s->err);
+        if (g == 0) m.own_chunk_sym = s->last_accel_sym;
       } else {                                           // every (own, visiting) pair once; the visitor's sums go to its owner
         // hop <= H: the whole own chunk x the whole visiting chunk. The hop half-way round an even ring (h = H + 1) is shared with the
         // visitor's owner: the lower device takes its own LOWER half x the whole visitor, the higher device its whole chunk x the visitor's
@@ -227,13 +229,17 @@ int refresh_acc(nb_ctx* c, double eps, double G, bool with_phi = false) {
     const size_t so = (size_t)m.cnt[o] * es;
     const int flags = (first ? 0 : NB_ACCUMULATE) | (m.uniform ? NB_UNIFORM_MASS : 0);
     double* phi = with_phi ? s->phi : nullptr;
+    int rc1;
     if (c->dtype == NB_F32)
-      return nb_launch_accel_f32(s, (const float*)field_ptr(s, 0), (const float*)field_ptr(s, 1), (const float*)field_ptr(s, 2), s->n,
-                                 (const float*)src, (const float*)(src + so), (const float*)(src + 2 * so), (const float*)(src + 3 * so), m.cnt[o],
-                                 (float)(eps * eps), (float)G, (float*)field_ptr(s, 7), (float*)field_ptr(s, 8), (float*)field_ptr(s, 9), flags, phi);
-    return nb_launch_accel_f64(s, (const double*)field_ptr(s, 0), (const double*)field_ptr(s, 1), (const double*)field_ptr(s, 2), s->n,
-                               (const double*)src, (const double*)(src + so), (const double*)(src + 2 * so), (const double*)(src + 3 * so), m.cnt[o],
-                               eps * eps, G, (double*)field_ptr(s, 7), (double*)field_ptr(s, 8), (double*)field_ptr(s, 9), flags, phi);
+      rc1 = nb_launch_accel_f32(s, (const float*)field_ptr(s, 0), (const float*)field_ptr(s, 1), (const float*)field_ptr(s, 2), s->n,
+                                (const float*)src, (const float*)(src + so), (const float*)(src + 2 * so), (const float*)(src + 3 * so), m.cnt[o],
+                                (float)(eps * eps), (float)G, (float*)field_ptr(s, 7), (float*)field_ptr(s, 8), (float*)field_ptr(s, 9), flags, phi);
+    else
+      rc1 = nb_launch_accel_f64(s, (const double*)field_ptr(s, 0), (const double*)field_ptr(s, 1), (const double*)field_ptr(s, 2), s->n,
+                                (const double*)src, (const double*)(src + so), (const double*)(src + 2 * so), (const double*)(src + 3 * so), m.cnt[o],
+                                eps * eps, G, (double*)field_ptr(s, 7), (double*)field_ptr(s, 8), (double*)field_ptr(s, 9), flags, phi);
+    if (first && g == 0) m.own_chunk_sym = s->last_accel_sym;     // the later cross-chunk launches of this schedule are one-sided by construction
+    return rc1;
   });
   if (rc) return rc;
   m.acc_valid = true; m.acc_eps = eps; m.acc_G = G;
@@ -520,9 +526,16 @@ int nb_multi_set_option(nb_ctx* c, int option, int64_t value) {
   return NB_OK;
 }
 
-// 1 if the last force evaluation ran the pair-symmetric kernels (every launch of the pair-symmetric schedule ends with one; the one-sided
-// schedule only for the own chunk)
+// nb_last_accel_symmetric of a multi-device context: the OWN-CHUNK launch of device 0 in the last force evaluation (the later launches of
+// the one-sided schedule are one-sided by construction; those of the pair-symmetric schedule fall back to two one-sided launches for very
+// small chunks — neither says which kernel the own chunk took, so it is recorded when that launch is made)
 int nb_multi_last_symmetric(const nb_ctx* c) {
   const nb_multi_state& m = *c->multi;
-  return (m.P > 0 && m.shard[0] && m.shard[0]->last_accel_sym) ? 1 : 0;
+  return m.own_chunk_sym ? 1 : 0;
+}
+
+// NB_QUERY_MULTI_SCHEDULE: 1 = the pair-symmetric schedule is what this context runs (more than one device and the option not switched off)
+int nb_multi_schedule_pairwise(const nb_ctx* c) {
+  const nb_multi_state& m = *c->multi;
+  return (m.P > 1 && m.pairwise != 0) ? 1 : 0;
 }

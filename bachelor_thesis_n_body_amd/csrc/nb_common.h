@@ -44,6 +44,7 @@ struct nb_ctx {
   double lr_eps = -1.0, lr_G = 0.0;
   // pair-symmetric self-interaction kernels (accel_sym_*.hip): per-context options (-1 = process default) and what the last launch took
   long long sym_enable = -1, sym_min_n = -1, sym_slab_bytes = -1;
+  long long sym_scratch_limit = -1;   // NB_OPT_SYM_SCRATCH_LIMIT: the most scratch the pair-symmetric kernels may ask the allocator for (-1: no limit)
   bool last_accel_sym = false;
   bool graph_replayed = false;   // the last nb_kdk_run replayed a captured step (diagnostic: nb_last_run_used_graph)
   // force solver used by nb_accel / nb_step: direct summation (default) or Barnes-Hut tree (fp32 only)
@@ -67,6 +68,10 @@ template <typename T> static inline T* st_ptr(nb_ctx* c, int field) {  // 0..9 =
 
 int nb_fail(nb_ctx* c, int code, const std::string& msg);
 int nb_ensure_work(nb_ctx* c, size_t bytes);
+// like nb_ensure_work, but a request the allocator refuses (or one above `limit` >= 0) is not an error: returns NB_WORK_UNAVAILABLE with the
+// HIP error cleared and the context's scratch released (the caller retries with a smaller request or takes another kernel)
+constexpr int NB_WORK_UNAVAILABLE = 1;
+int nb_try_ensure_work(nb_ctx* c, size_t bytes, long long limit);
 
 #define NB_HIP(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
   return nb_fail((c), NB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
@@ -125,6 +130,7 @@ int nb_multi_step_energy(nb_ctx* c, double dt, int64_t nsteps, double eps, doubl
 int nb_multi_sync(nb_ctx* c);
 int nb_multi_set_option(nb_ctx* c, int option, int64_t value);
 int nb_multi_last_symmetric(const nb_ctx* c);
+int nb_multi_schedule_pairwise(const nb_ctx* c);
 int nb_multi_info(const nb_ctx* c, int which, int64_t* out, int cap);
 int nb_bh_check(nb_ctx* c);   // call after a stream sync
 int nb_launch_potential_f32(nb_ctx* c, const float* xi, const float* yi, const float* zi, const float* mi,

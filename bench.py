@@ -405,7 +405,8 @@ def single_process(args) -> int:
         t0 = time.perf_counter()
         eng.step(dt, args.steps, eps, G)          # ONE call: no host synchronisation between the steps; returns synchronised
         elapsed = time.perf_counter() - t0
-        symmetric = eng.last_accel_symmetric()
+        symmetric = eng.last_accel_symmetric()                  # the own-chunk launch of device 0
+        pairwise = bool(eng.get_option("multi_schedule"))       # the schedule the context runs: its option, not a guess from the last launch
     value = float(args.n) * float(args.n) * args.steps / elapsed
     peak = PEAK_FP32_VECTOR_TFLOPS if args.dtype == "f32" else PEAK_FP64_VECTOR_TFLOPS
     achieved = value * FLOP_PER_INTERACTION / 1e12 / len(devices)
@@ -418,7 +419,8 @@ def single_process(args) -> int:
            "world_size": args.gpus, "backend": "hipMemcpyPeerAsync (single process)", "same_device": bool(args.same_device), "ring": None,
            "roofline": {"bound": "vector_" + ("fp32" if args.dtype == "f32" else "fp64"),
                         "kernel": ("accel_sym_%s_kernel" if symmetric else "accel_%s_kernel") % args.dtype, "pair_symmetry": bool(symmetric),
-                        "schedule": "pair-symmetric: each pair of chunks worked on by one owner, partial sums pushed to the other" if symmetric else "one-sided",
+                        "pair_symmetry_scope": None if not symmetric else ("every launch" if (pairwise or args.gpus == 1) else "own-chunk launch of each device only"),
+                        "schedule": None if args.gpus == 1 else ("pair-symmetric: each pair of chunks worked on by one owner, partial sums pushed to the other" if pairwise else "one-sided: every device sums all chunks for its own sinks"),
                         "variant": "general" if args.general_mass else "uniform_mass", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                         "frac": achieved / peak, "flop_per_interaction": FLOP_PER_INTERACTION,
                         "note": "per device, from the whole step (exchange and O(N) kernels included); kernel events are not visible from outside the library",

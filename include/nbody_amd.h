@@ -131,14 +131,31 @@ int nb_last_run_used_graph(const nb_ctx* ctx);
  * accel_sym_f64.hip); results agree with the one-sided kernels to rounding (different summation order). Options of a context:
  *   NB_OPT_PAIR_SYMMETRY : 1 = use them where they apply (default; process-wide default from NB_F32_SYM / NB_F64_SYM), 0 = one-sided kernels only
  *   NB_OPT_SYM_MIN_N     : smallest n that takes them (default 32768 fp32 / 16384 fp64: below, the one-sided kernel is faster)
- *   NB_OPT_SYM_SLAB_BYTES: scratch budget for the per-offset partial-sum slabs (default 4 GiB); larger problems run in several passes
+ *   NB_OPT_SYM_SLAB_BYTES: scratch budget for the per-offset partial-sum slabs (default 4 GiB); larger problems run in several passes.
+ *                          The budget covers the slabs only: the per-group sink sums (up to ~100 MB at N = 2^20), the fp64 totals of a
+ *                          multi-pass launch and 25 % allocation headroom come on top (N = 2^20 fp32: ~3 GB per context in all)
+ *   NB_OPT_SYM_SCRATCH_LIMIT: the most scratch (bytes, everything included) these kernels may ask the allocator for (default: no limit).
+ *                          When a request is above the limit or the allocator refuses it, the launch halves its slab slots per pass until
+ *                          it fits, and if even one slot does not fit the one-sided kernel (megabytes of scratch) runs instead —
+ *                          an out-of-memory condition never fails a force evaluation that the one-sided kernel could do
  * value < 0 restores the default. No counterpart in the reference (CONCEPT's pp solver is not in the repository). */
 #define NB_OPT_PAIR_SYMMETRY 1
 #define NB_OPT_SYM_MIN_N 2
 #define NB_OPT_SYM_SLAB_BYTES 3
+#define NB_OPT_SYM_SCRATCH_LIMIT 4
 int nb_set_option(nb_ctx* ctx, int option, int64_t value);
-/* 1 if the last direct-summation force launch of this context ran the pair-symmetric kernel, 0 if the one-sided one */
+/* 1 if the last direct-summation force launch of this context ran the pair-symmetric kernel, 0 if the one-sided one. A multi-device context
+ * (nb_create_multi) answers for the OWN-CHUNK launch of its first device in the last force evaluation — the later launches of an evaluation
+ * say nothing about it (one-sided by construction in the one-sided schedule; two one-sided launches instead of a two-block one for very small
+ * chunks in the pair-symmetric schedule); which SCHEDULE the context runs is NB_QUERY_MULTI_SCHEDULE below. */
 int nb_last_accel_symmetric(const nb_ctx* ctx);
+/* Read back an option as set (-1 = default in force), or one of the read-only queries:
+ *   NB_QUERY_MULTI_SCHEDULE      : 1 = a multi-device context that runs the pair-symmetric schedule (each pair of chunks worked on by one of its
+ *                                  owners, partial sums pushed to the other), 0 = the one-sided schedule or a single-device context
+ *   NB_QUERY_OWN_CHUNK_SYMMETRIC : what nb_last_accel_symmetric returns */
+#define NB_QUERY_MULTI_SCHEDULE 100
+#define NB_QUERY_OWN_CHUNK_SYMMETRIC 101
+int nb_get_option(const nb_ctx* ctx, int option, int64_t* value);
 
 /* ---- measurement aid ("reported absolute and as a fraction of the vector-FP32 roofline") ----
  * Sustained shader clock of `device` over the next `window_ms` milliseconds at most (clamped to 5 s), measured by one sleeping wave on a private
@@ -153,7 +170,12 @@ int nb_clock_probe_begin(int device, double window_ms, nb_clock_probe** probe);
 int nb_clock_probe_stop(nb_clock_probe* probe, void* stream);
 int nb_clock_probe_end(nb_clock_probe* probe, double* mhz, double* window_ms);
 
-/* ---- host-pointer surface: the drop-in compute_forces()/step()/energy() (SURVEY §8a ⊕1-⊕3) ---- */
+/* ---- host-pointer surface: the drop-in compute_forces()/step()/energy() (SURVEY §8a ⊕1-⊕3) ----
+ * "Host-pointer" = the caller hands over HOST buffers, which are copied to the device; the arithmetic always runs on the GPU. The
+ * `nb_accel_host_*` entry points sketched in SURVEY.md §8(b) / §7.1 step 2 (a CPU build of the same kernel behind this ABI) are
+ * deliberately NOT part of this library: a CPU path inside the product would be exactly the silent fallback the parity claims rule out.
+ * The CPU build of the kernel exists as test infrastructure only — oracle/nbody_oracle.c (nbo_accel_f64_omp / nbo_accel_f32_omp: OpenMP +
+ * SIMD, same argument order) — and is what bench.py's `cpu_baseline` leg times. */
 int nb_set_state(nb_ctx* ctx, const void* x, const void* y, const void* z,
                  const void* vx, const void* vy, const void* vz, const void* m);
 int nb_get_state(nb_ctx* ctx, void* x, void* y, void* z, void* vx, void* vy, void* vz, void* m);

@@ -104,7 +104,8 @@ void nbo_accel_f32_omp(int64_t n_snk, const float* xi, const float* yi, const fl
   }
 }
 
-/* sum_i m_i sum_{j != i} m_j / sqrt(r_ij^2 + eps^2), times -G/2 */
+/* sum_i m_i sum_{j != i} m_j / sqrt(r_ij^2 + eps^2), times -G/2; a pair with a zero denominator (coincident particles at eps = 0)
+ * is skipped, as it is in the force sum */
 double nbo_potential_f64(int64_t n, const double* x, const double* y, const double* z, const double* m,
                          double eps, double G) {
   const double eps2 = eps * eps;
@@ -115,11 +116,31 @@ double nbo_potential_f64(int64_t n, const double* x, const double* y, const doub
     for (int64_t j = 0; j < n; ++j) {
       if (j == i) continue;
       const double dx = x[j] - x[i], dy = y[j] - y[i], dz = z[j] - z[i];
-      s += m[j] / sqrt(dx * dx + dy * dy + dz * dz + eps2);
+      const double r2 = dx * dx + dy * dy + dz * dz + eps2;
+      if (r2 > 0.0) s += m[j] / sqrt(r2);
     }
     total += m[i] * s;
   }
   return -0.5 * G * total;
+}
+
+/* phi_i = sum_j m_j / sqrt(|r_j - r_i|^2 + eps^2) of n_snk sinks over n_src sources, EVERY source counted (a sink that is also a source
+ * contributes its own m_i / eps — the convention of the fused force + potential kernels, which remove that term afterwards); pairs with
+ * a zero denominator skipped. No G, no sign. */
+void nbo_phi_f64_omp(int64_t n_snk, const double* xi, const double* yi, const double* zi,
+                     int64_t n_src, const double* xs, const double* ys, const double* zs, const double* ms,
+                     double eps, double* phi) {
+  const double eps2 = eps * eps;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n_snk; ++i) {
+    double s = 0.0;
+    for (int64_t j = 0; j < n_src; ++j) {
+      const double dx = xs[j] - xi[i], dy = ys[j] - yi[i], dz = zs[j] - zi[i];
+      const double r2 = dx * dx + dy * dy + dz * dz + eps2;
+      if (r2 > 0.0) s += ms[j] / sqrt(r2);
+    }
+    phi[i] = s;
+  }
 }
 
 double nbo_kinetic_f64(int64_t n, const double* vx, const double* vy, const double* vz, const double* m) {

@@ -17,7 +17,7 @@ scalar-loop C restatement in oracle/nbody_oracle.c (tests/golden/).
 
 Definitions:
   a_i = G * sum_j m_j (r_j - r_i) / (|r_j - r_i|^2 + eps^2)^{3/2}     (pairs with zero denominator skipped)
-  U   = -G/2 * sum_i sum_{j != i} m_i m_j / sqrt(|r_j - r_i|^2 + eps^2)
+  U   = -G/2 * sum_i sum_{j != i} m_i m_j / sqrt(|r_j - r_i|^2 + eps^2)            (pairs with zero denominator skipped)
   KDK : v += a*dt/2 ; x += v*dt ; a = compute_forces(x) ; v += a*dt/2     (a cached between steps)
 """
 from __future__ import annotations
@@ -89,7 +89,7 @@ def potential_energy(pos, mass, eps: float, G: float = 1.0) -> float:
         d = pos[None, :, :] - pos[i0:i1, None, :]
         r2 = np.einsum("ijk,ijk->ij", d, d) + eps2
         with np.errstate(divide="ignore"):
-            w = mass[None, :] / np.sqrt(r2)
+            w = np.where(r2 > 0.0, mass[None, :] / np.sqrt(r2), 0.0)     # a pair with a zero denominator is skipped, as in the force sum
         w[np.arange(i1 - i0), np.arange(i0, i1)] = 0.0      # j != i
         total += float(np.dot(mass[i0:i1], w.sum(axis=1)))
     return -0.5 * G * total

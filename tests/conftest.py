@@ -81,6 +81,17 @@ class COracle:
         return float(self.lib.nbo_potential_f64(C.c_int64(p.shape[1]), v(p[0]), v(p[1]), v(p[2]), v(m),
                                                 C.c_double(eps), C.c_double(G)))
 
+    def phi(self, pos, mass, eps, sinks):
+        """phi_i = sum_j m_j / sqrt(r_ij^2 + eps^2) of `sinks` over all sources (a sink's own m_i / eps included when it is a source)."""
+        p = np.ascontiguousarray(np.asarray(pos, np.float64).T)
+        m = np.ascontiguousarray(mass, np.float64)
+        s = np.ascontiguousarray(np.asarray(sinks, np.float64).T)
+        out = np.zeros(s.shape[1])
+        v = self._vp
+        self.lib.nbo_phi_f64_omp(C.c_int64(s.shape[1]), v(s[0]), v(s[1]), v(s[2]), C.c_int64(p.shape[1]), v(p[0]), v(p[1]), v(p[2]), v(m),
+                                 C.c_double(eps), v(out))
+        return out
+
     def kinetic(self, vel, mass):
         q = np.ascontiguousarray(np.asarray(vel, np.float64).T)
         m = np.ascontiguousarray(mass, np.float64)

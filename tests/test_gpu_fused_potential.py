@@ -9,7 +9,7 @@ from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 DTYPES = [np.float32, np.float64]
-TOL = {np.float32: 2e-5, np.float64: 1e-11}
+TOL = {np.float32: 3e-6, np.float64: 1e-11}      # phi_i: fp32 terms, per-tile fp64 flush (measured <= 6e-7)
 
 
 def _phi_ref(snk, src, m, eps):

@@ -46,7 +46,7 @@ def test_multi_device_context_matches_single_device_and_oracle(dtype, P, n, unif
         np.testing.assert_array_equal(e.cached_acc(), e.cached_acc())
     tol = 3e-6 if dtype == np.float32 else 1e-12
     assert np.abs(aP - a1).max() < tol * np.abs(a1).max()
-    assert rel_err(aP, ora.compute_forces(s.pos.astype(np.float64), s.mass.astype(np.float64), 0.01)).max() < (2e-5 if dtype == np.float32 else 1e-10)
+    assert rel_err(aP, ora.compute_forces(s.pos.astype(np.float64), s.mass.astype(np.float64), 0.01)).max() < (3e-6 if dtype == np.float32 else 1e-10)
     assert np.abs(got.pos - ref.pos).max() < 10 * tol and np.abs(got.vel - ref.vel).max() < 10 * tol
     np.testing.assert_array_equal(got.mass, ref.mass)
     assert kP == pytest.approx(k1, rel=1e-12) and uP == pytest.approx(u1, rel=3e-6 if dtype == np.float32 else 1e-12)
@@ -127,3 +127,33 @@ def test_multi_context_rejects_what_it_does_not_support_and_bad_arguments():
             e.cached_acc()                                   # state, but no force evaluation yet
     with nb.Engine(64, np.float32) as e:                     # a plain context reports one device
         assert e.layout() == ([64], [0])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_multi_context_reports_schedule_and_own_chunk_kernel_separately(dtype):
+    """nb_get_option(NB_QUERY_MULTI_SCHEDULE) is the schedule the context RUNS (its option); nb_last_accel_symmetric is the own-chunk launch
+    of device 0 — in the one-sided schedule the later cross-chunk launches (one-sided by construction) must not overwrite it, and in the
+    pair-symmetric schedule small chunks whose two-block hop falls back to one-sided launches must not either."""
+    n = 3 * 40000
+    s = nb.plummer_sphere(n, 3, dtype)
+    with nb.Engine(n, dtype, devices=[0, 0, 0]) as e:
+        e.set_state(s)
+        assert e.get_option("multi_schedule") == 1 and e.get_option("pair_symmetry") == -1
+        a_pair = e.accel(0.01)
+        assert e.last_accel_symmetric() and e.get_option("own_chunk_symmetric") == 1        # chunks of 40 000: the pair-symmetric kernel
+        e.set_option("pair_symmetry", 0)                      # one-sided schedule AND one-sided kernels
+        assert e.get_option("multi_schedule") == 0
+        a_one = e.accel(0.01)
+        assert not e.last_accel_symmetric()
+        e.set_option("pair_symmetry", -1)
+        assert e.get_option("multi_schedule") == 1
+    assert rel_err(a_pair, a_one.astype(np.float64)).max() < (1e-6 if dtype == np.float32 else 2e-13)
+    with nb.Engine(40000, dtype) as e:                        # a single-device context runs no multi-device schedule
+        e.set_state(nb.plummer_sphere(40000, 3, dtype))
+        e.accel(0.01, fetch=False)
+        assert e.get_option("multi_schedule") == 0 and e.get_option("own_chunk_symmetric") == 1
+    n = 3 * 9000                                              # own chunks of 9000 < sym_min_n: own chunk one-sided, hops fall back too
+    with nb.Engine(n, dtype, devices=[0, 0, 0]) as e:
+        e.set_state(nb.plummer_sphere(n, 4, dtype))
+        e.accel(0.01, fetch=False)
+        assert e.get_option("multi_schedule") == 1 and not e.last_accel_symmetric()

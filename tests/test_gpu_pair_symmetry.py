@@ -2,7 +2,10 @@
 once) against the C oracle on the same inputs, against the one-sided kernels they replace, and through their own invariants: Newton's third
 law, bit-reproducibility, independence of the number of slab passes. All calls go through the C-ABI (ctypes -> libnbody_amd.so).
 
-Tolerances as in test_gpu_parity.py: fp64 <= 2e-13, fp32 <= 2e-5 of |a_i| against the fp64 oracle on the same (rounded) inputs."""
+Tolerances (per-particle |da| / |a| against the fp64 oracle on the same rounded inputs): fp64 <= 2e-13; fp32 <= 1e-6 from n = 32768 on
+(measured 8e-8 .. 2e-7, profiles/r03_sym_kernel_development_log.txt: fp32 pair terms, partial sums flushed to fp64 per tile / set) and
+<= 3e-6 below (measured up to 1.3e-6 at n = 4096 .. 16384, where a few central particles have |a| far below the typical pair term) —
+within 5x of what is measured, so a lost flush or a mis-added slab fails."""
 import numpy as np
 import pytest
 
@@ -10,7 +13,11 @@ import bachelor_thesis_n_body_amd as nb
 from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
-TOL = {np.float32: 2e-5, np.float64: 2e-13}
+TOL = {np.float32: 3e-6, np.float64: 2e-13}
+
+
+def tol(dtype, n):
+    return 1e-6 if (dtype == np.float32 and n >= 32768) else TOL[dtype]
 DTYPES = [np.float32, np.float64]
 
 
@@ -49,13 +56,15 @@ def test_symmetric_kernel_matches_oracle(dtype, general, n, coracle):
     idx = np.arange(n) if n <= 20000 else _sample(n)
     ref = coracle.accel(s.pos.astype(np.float64), s.mass.astype(np.float64), 0.01, sinks=s.pos[idx].astype(np.float64))
     err = rel_err(a[idx], ref)
-    assert np.isfinite(a).all() and err.max() < TOL[dtype], f"max {err.max():.3e} median {np.median(err):.3e}"
+    assert np.isfinite(a).all() and err.max() < tol(dtype, n), f"max {err.max():.3e} median {np.median(err):.3e}"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("general", [False, True])
-@pytest.mark.parametrize("n", [3000, 50000, 262144])
+@pytest.mark.parametrize("n", [3000, 50000, 262144, 1 << 20])
 def test_symmetric_and_one_sided_kernels_agree_to_rounding(dtype, general, n):
+    """EVERY sink of the set, up to the headline size: the two kernels share no partial-sum structure (sets x offsets x tiles with slabs
+    against sink blocks x source splits), so a mis-added slab or a dropped tile of either shows up here."""
     s = _cloud(n, dtype, general, seed=5)
     with _engine(n, dtype, s) as e:
         a_sym = e.accel(0.02, G=1.7)
@@ -68,7 +77,7 @@ def test_symmetric_and_one_sided_kernels_agree_to_rounding(dtype, general, n):
         assert e.last_accel_symmetric()
     # both sum the same pair terms, in different orders, with fp32 partials flushed to fp64 (fp32) / plain fp64
     d = rel_err(a_sym, a_one.astype(np.float64))
-    assert d.max() < (3e-6 if dtype == np.float32 else 2e-13), f"{d.max():.3e}"
+    assert d.max() < ((3e-6 if n < 32768 else 1e-6) if dtype == np.float32 else 2e-13), f"{d.max():.3e}"
     assert np.array_equal(a_sym, a_again), "the pair-symmetric kernel is not bit-reproducible"
 
 
@@ -98,6 +107,53 @@ def test_result_does_not_depend_on_the_number_of_slab_passes(dtype, general):
         assert e.last_accel_symmetric()
     d = rel_err(a2, a1.astype(np.float64))
     assert d.max() < (2e-7 if dtype == np.float32 else 1e-14), f"{d.max():.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_scratch_budget_extremes_and_allocator_refusal(dtype):
+    """A slab budget meant as 'unlimited' (INT64_MAX) must not wrap in the slots-per-pass arithmetic; a scratch limit below the default
+    request makes the launch halve its slots per pass until it fits (still pair-symmetric, same result to the fp64 order of the slabs); a
+    limit below even ONE slot hands the evaluation to the one-sided kernel instead of failing it."""
+    n = 60000
+    s = _cloud(n, dtype, False, seed=9)
+    with _engine(n, dtype, s) as e:
+        a0 = e.accel(0.01)
+        assert e.last_accel_symmetric() and e.get_option("sym_scratch_limit") == -1
+        e.set_option("sym_slab_bytes", (1 << 63) - 1)
+        a1 = e.accel(0.01)
+        assert e.last_accel_symmetric() and np.array_equal(a1, a0)
+        e.set_option("sym_slab_bytes", -1)
+        e.set_option("sym_scratch_limit", 24 << 20)          # the one-pass request is ~60 MB (fp32) / ~110 MB (fp64) here
+        assert e.get_option("sym_scratch_limit") == 24 << 20
+        a2 = e.accel(0.01)
+        assert e.last_accel_symmetric()
+        e.set_option("sym_scratch_limit", 1 << 20)           # not even the sink-sum slab fits: one-sided kernel
+        a3 = e.accel(0.01)
+        assert not e.last_accel_symmetric()
+        e.set_option("sym_scratch_limit", -1)
+        a4 = e.accel(0.01)
+        assert e.last_accel_symmetric() and np.array_equal(a4, a0)
+    t = 1e-6 if dtype == np.float32 else 2e-13
+    assert rel_err(a2, a0.astype(np.float64)).max() < (2e-7 if dtype == np.float32 else 1e-14)
+    assert rel_err(a3, a0.astype(np.float64)).max() < t
+    # the two-block entry under the same limits
+    import torch
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    k = nb.HipKernels(0)
+    na = 30000
+    blk = lambda lo, hi: torch.from_numpy(np.vstack([s.pos[lo:hi].T, s.mass[None, lo:hi]])).contiguous().cuda()
+    A, B = blk(0, na), blk(na, n)
+    res = []
+    for limit, sym in ((-1, True), (12 << 20, True), (1 << 18, False)):
+        k.set_option("sym_scratch_limit", limit)
+        acc_a, acc_b = torch.zeros((3, na), dtype=tdt, device="cuda"), torch.zeros((3, n - na), dtype=tdt, device="cuda")
+        k.accel_pair(A, na, B, n - na, 0.01, 1.0, acc_a, acc_b, False, uniform_mass=True)
+        assert k.last_accel_symmetric() == sym, limit
+        torch.cuda.synchronize()
+        res.append((acc_a.cpu().numpy().T.astype(np.float64), acc_b.cpu().numpy().T.astype(np.float64)))
+    for ra, rb in res[1:]:
+        assert rel_err(ra, res[0][0]).max() < t and rel_err(rb, res[0][1]).max() < t
+    k.close()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -180,9 +236,9 @@ def test_headline_size_fp32_sampled(coracle):
         e.set_state(s)
         a = e.accel(0.01)
         assert e.last_accel_symmetric()
-    idx = _sample(n, 96)
+    idx = _sample(n, 3000)              # ~3000 sinks x 2^20 sources: half a second of the C oracle
     ref = coracle.accel(s.pos.astype(np.float64), s.mass.astype(np.float64), 0.01, sinks=s.pos[idx].astype(np.float64))
-    assert rel_err(a[idx], ref).max() < 2e-5
+    assert rel_err(a[idx], ref).max() < 1e-6
     m = s.mass.astype(np.float64)[:, None]
     assert np.abs((m * a).sum(0)).max() / np.abs(m * a).sum(0).max() < 1e-9
 
@@ -230,8 +286,7 @@ def test_two_block_entry_matches_oracle(dtype, general, na, nb_, force, coracle)
     ref_a = coracle.accel(p64[na:], m64[na:], 0.01, 1.3, sinks=p64[:na][ia])
     ref_b = coracle.accel(p64[:na], m64[:na], 0.01, 1.3, sinks=p64[na:][ib])
     ga, gb = first.cpu().numpy().T[ia], acc_b.cpu().numpy().T[ib]
-    tol = TOL[dtype]
-    assert rel_err(ga, ref_a).max() < tol and rel_err(gb, ref_b).max() < tol
+    assert rel_err(ga, ref_a).max() < tol(dtype, min(na, nb_)) and rel_err(gb, ref_b).max() < tol(dtype, min(na, nb_))
     assert torch.allclose(acc_a, 2 * first, rtol=1e-6 if dtype == np.float32 else 1e-15, atol=0)
     # momentum exchanged between the blocks cancels: sum m_a a_a = - sum m_b a_b (exactly the same pair terms on both sides)
     pa = (m64[:na, None] * first.cpu().numpy().T.astype(np.float64)).sum(0)
@@ -300,4 +355,4 @@ def test_symmetric_kernel_matches_committed_golden_vectors(name):
         a = e.accel(float(g[f"{name}_eps"]), float(g[f"{name}_G"]))
         assert e.last_accel_symmetric()
     err = rel_err(a[g[f"{name}_idx"]], g[f"{name}_acc"])
-    assert err.max() < TOL[dtype], f"{name}: {err.max():.3e}"
+    assert err.max() < tol(dtype, n), f"{name}: {err.max():.3e}"

@@ -6,8 +6,9 @@ mass and G, time reversibility, source-split / chunk-accumulate consistency).
 Tolerances (written here, SURVEY.md §8d "Parity gates"):
   fp64 kernel vs fp64 oracle : per-particle |da|/|a| <= 2e-13   (north_star bar: 1e-6; measured 1e-14 .. 2.3e-14 — the first-order
   rsqrt refinement of accel_f64.hip; 1e-13 is its documented contract)
-  fp32 kernel vs fp64 oracle on the SAME fp32-rounded inputs : <= 2e-5 (measured ~1e-6 thanks to the per-tile
-  fp64 flush of the fp32 partial sums; plain fp32 accumulation would be ~1e-4 at these N)
+  fp32 kernel vs fp64 oracle on the SAME fp32-rounded inputs : <= 3e-6, and <= 1e-6 from n = 32768 on (measured 1.3e-6 at n = 4096 and
+  16384, 8e-8 .. 2e-7 at large n thanks to the per-tile fp64 flush of the fp32 partial sums; plain fp32 accumulation would be ~1e-4 at
+  these N) — within 5x of the measured errors, so losing the flush fails
 """
 from pathlib import Path
 
@@ -21,7 +22,8 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 GOLD = Path(__file__).resolve().parent / "golden"
-TOL = {np.float32: 2e-5, np.float64: 2e-13}
+TOL = {np.float32: 3e-6, np.float64: 2e-13}
+TOL_LARGE = {np.float32: 1e-6, np.float64: 2e-13}      # n >= 32768
 DTYPES = [np.float32, np.float64]
 
 
@@ -63,7 +65,7 @@ def test_accel_matches_oracle_config1(dtype, n, coracle):
     a = nb.compute_forces(s.pos, s.mass, 0.01)
     ref = _ref(s, 0.01, coracle=coracle)
     e = rel_err(a, ref)
-    if not e.max() < TOL[dtype]:
+    if not e.max() < (TOL_LARGE if n >= 32768 else TOL)[dtype]:
         # say WHICH side is off: a second GPU evaluation and an independent NumPy-oracle subset
         a2 = nb.compute_forces(s.pos, s.mass, 0.01)
         idx = np.arange(0, n, max(1, n // 64))
@@ -105,7 +107,7 @@ def test_accel_matches_golden_vectors(name):
     assert rel_err(a64, g[f"{name}_acc"]).max() < 1e-10
     a32 = nb.compute_forces(pos.astype(np.float32), mass.astype(np.float32), eps, G)
     ref32 = ora.compute_forces(pos.astype(np.float32).astype(np.float64), mass.astype(np.float32).astype(np.float64), eps, G)
-    assert rel_err(a32, ref32).max() < 2e-5
+    assert rel_err(a32, ref32).max() < TOL[np.float32]
     with nb.Engine(len(mass), np.float64) as e:
         e.set_state(nb.State(pos, g[f"{name}_vel"], mass))
         k, u = e.energy(eps, G)
@@ -251,10 +253,10 @@ def test_full_size_properties(dtype, n):
     # sampled sinks against the oracle (all N sources)
     idx = np.random.default_rng(0).choice(n, 64, replace=False)
     ref = ora.compute_forces(s.pos.astype(np.float64), m64, 0.01, sinks=s.pos[idx].astype(np.float64))
-    assert rel_err(a[idx], ref).max() < TOL[dtype]
-    # permutation invariance: reversed particle order gives the reversed result
+    assert rel_err(a[idx], ref).max() < TOL_LARGE[dtype]
+    # permutation invariance: reversed particle order gives the reversed result (another summation order: twice the rounding)
     ar = nb.compute_forces(s.pos[::-1].copy(), s.mass[::-1].copy(), 0.01)[::-1]
-    assert rel_err(ar, a).max() < (2e-5 if dtype == np.float32 else 1e-11)
+    assert rel_err(ar, a).max() < (2e-6 if dtype == np.float32 else 1e-11)
 
 
 # ------------------------------------------------------------------ hipGraph replay of the step loop

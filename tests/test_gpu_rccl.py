@@ -40,7 +40,7 @@ CODE = textwrap.dedent("""
                 ref = e.accel(0.01)
             eng = VirtualRingEngine(n, dtype, device=torch.device("cuda", 0), virtual_world=P, pairwise=pairwise)
             assert dist.get_backend() == "nccl" and eng.world == P and eng.n_loc == eng.counts[0] and eng.pairwise == pairwise
-            assert eng.split_half == (pairwise and P % 2 == 0)
+            assert eng.split_half == (pairwise and P %% 2 == 0)
             eng.set_state(s)
             probe = HopProbe(torch, torch.device("cuda", 0)); eng.hop_probe = probe; probe.enabled = True
             for rep in range(4):                      # repeated evaluations: every receive buffer is reused under the communicator's ordering

@@ -140,3 +140,27 @@ def test_plummer_virial_and_energy(coracle):
     assert abs(2 * k / abs(u) - 1.0) < 0.05
     assert abs((k + u) + 0.25) < 0.02
     # the radius cut at 10a removes ~1% of the mass from the tail: U is slightly shallower than -1/2... checked loosely
+
+
+def test_phi_per_sink_and_zero_denominator_rule(coracle):
+    """The per-sink potential of the C restatement (checker of the fused force + potential kernels): U = -G/2 sum_i m_i (phi_i - m_i / eps),
+    two-body closed form, and the rule both restatements share with the force sum — a pair with a zero denominator is skipped."""
+    s = plummer_sphere(700, 12)
+    m = s.mass * np.random.default_rng(0).uniform(0.5, 2.0, s.n)
+    eps = 0.03
+    phi = coracle.phi(s.pos, m, eps, s.pos)
+    u = -0.5 * float((m * (phi - m / eps)).sum())
+    assert u == pytest.approx(coracle.potential(s.pos, m, eps), rel=1e-13) and u == pytest.approx(ora.potential_energy(s.pos, m, eps), rel=1e-13)
+    two = np.array([[0.0, 0, 0], [3.0, 4.0, 0]])
+    assert coracle.phi(two, np.array([2.0, 5.0]), 0.0, two) == pytest.approx([5.0 / 5.0, 2.0 / 5.0], rel=1e-15)
+    # eps = 0 and coincident particles: finite, the coincident pair dropped by both restatements
+    pos = s.pos.copy()
+    pos[11] = pos[400]
+    uc, un = coracle.potential(pos, m, 0.0), ora.potential_energy(pos, m, 0.0)
+    assert np.isfinite(uc) and uc == pytest.approx(un, rel=1e-13)
+    keep = np.ones(s.n, bool)
+    keep[400] = False
+    # ... = the system without particle 400, plus 400's pairs with everything except 11
+    d = np.linalg.norm(pos[keep] - pos[400], axis=1)
+    extra = -m[400] * float((m[keep][d > 0] / d[d > 0]).sum())
+    assert uc == pytest.approx(coracle.potential(pos[keep], m[keep], 0.0) + extra, rel=1e-12)
