@@ -27,7 +27,7 @@ import numpy as np
 from . import params as _params
 
 
-def _write_powerspec(path: Path, k, pk, counts, a: float, ngrid: int, corrected=None, linear=None) -> None:
+def _write_powerspec(path: Path, k, pk, counts, a: float, ngrid: int, corrected=None, linear=None, digits: int = 8) -> None:
     """Text table in the layout of CONCEPT's powerspec files — k, modes, P, P corrected, P linear
     (PPPMP3M/PP/powerspec/powerspec_a=1.00:1-26) — so that the thesis' loaders, which read columns (0, 2, 3, 4)
     (PPPMP3M/pppmp3mplotter.py:123-134, SnapVsPK/Power_compare.py:625-629), open it unchanged. Unknown columns hold nan."""
@@ -38,8 +38,9 @@ def _write_powerspec(path: Path, k, pk, counts, a: float, ngrid: int, corrected=
         fh.write(f"# Power spectrum from bachelor_thesis_n_body_amd at a = {a:g}\n#\n# Components:\n#   0: matter  (upstream grid size {ngrid})\n#\n")
         fh.write(f"#                          grid size {ngrid}\n#                      component 0    (corrected)      (linear)\n")
         fh.write("#  k [Mpc⁻¹]   modes     P [Mpc³]       P [Mpc³]       P [Mpc³]\n")
+        d = max(1, int(digits) - 1)          # powerspec_options['significant figures'] (default 8, as the reference's tables)
         for ki, ci, pi, pc, pl in zip(k, counts, pk, corrected, linear):
-            fh.write(f"{ki:.7e} {int(ci):6d}  {pi:.7e}  {pc:.7e}  {pl:.7e}\n")
+            fh.write(f"{ki:.{d}e} {int(ci):6d}  {pi:.{d}e}  {pc:.{d}e}  {pl:.{d}e}\n")
 
 
 def _load_pk_table(args, s) -> np.ndarray:
@@ -119,8 +120,14 @@ def _run_cosmological(args, p, s) -> int:
                                     extra_attrs={"a": float(a1), "H0": float(p["H0"]), "Ωb": float(p["Ωb"]), "Ωcdm": float(p["Ωcdm"])})
         if a1 in ps_t:
             pdir = Path(s["powerspec_dir"] or out.parent / "powerspec"); pdir.mkdir(parents=True, exist_ok=True)
-            kk, cnt, pk, pcorr, plin = cosmo.concept_power_table(pos, L, n_side, table, c.growth(a1)[0], noise_power)
-            _write_powerspec(pdir / f"powerspec_a={a1:.2f}", kk, pk, cnt, a1, n_side, pcorr, plin)
+            po = s["powerspec"]              # powerspec_options of the parameter file (params.powerspec_options)
+            grid = po["gridsize"] or n_side
+            kk, cnt, pk, pcorr, plin = cosmo.concept_power_table(pos, L, grid, table, c.growth(a1)[0], noise_power if grid == n_side else None,
+                                                                 bins_per_decade=po["bins_per_decade"], k_max=min(po["k_max"], np.pi * grid / L),
+                                                                 interlace=po["interlace"], deconvolve=po["deconvolve"])
+            if not po["realization_correction"]:
+                pcorr = np.full_like(pk, np.nan)
+            _write_powerspec(pdir / f"powerspec_a={a1:.2f}", kk, pk, cnt, a1, grid, pcorr, plin, po["significant_figures"])
         a0 = a1
     print(f"concept: cosmological {s['gravity']} run finished at a = {a0:g}; {len(snap_t)} snapshot(s) in {out}")
     return 0

@@ -160,19 +160,47 @@ def zeldovich_ics(pk_table, n_side: int, boxsize: float, cosmo: Cosmology, a_beg
     return pos, vel
 
 
-def concept_power_table(pos, boxsize: float, ngrid: int, pk_table=None, growth: float = 1.0, noise_power=None, nbins: Optional[int] = None):
+def bins_per_decade_edges(table, k_min: float, k_max: float) -> np.ndarray:
+    """Bin edges for `powerspec_options['bins per decade']` (SnapVsPK/Uncertain.param:50-55: {'4*k_min': 4, '100*k_min': 40}, the default
+    CONCEPT's documentation gives): the local bin density d(k) is interpolated linearly in log k between the given (k, bins per decade)
+    points and held constant outside them; bin CENTRES start at k_min and follow c' = c * 10^(1 / d(c)); edges sit at the geometric means
+    of neighbouring centres (the first one half a bin below k_min), the last edge is k_max, a remainder narrower than half a bin joins
+    the bin before it. CONCEPT's own routine is not in the repository: for the reference's 64^3 / 500 Mpc tables this rule gives the
+    same 16 bins, the first three mode counts (3, 25, 124) exactly and the others to <= 10 % (PPPMP3M/PP/powerspec/powerspec_a=1.00:11-26;
+    tests/test_params_cli.py)."""
+    pts = sorted((float(k), float(b)) for k, b in table)
+    lk, nb = np.log([k for k, _ in pts]), [b for _, b in pts]
+    dens = lambda k: float(np.interp(np.log(k), lk, nb))
+    c = [float(k_min)]
+    while c[-1] < k_max:
+        c.append(c[-1] * 10.0 ** (1.0 / dens(c[-1])))
+    e = [c[0] / np.sqrt(c[1] / c[0])] + [np.sqrt(c[i] * c[i + 1]) for i in range(len(c) - 1)]
+    e = [x for x in e if x < k_max]
+    if len(e) >= 2 and (k_max / e[-1]) < np.sqrt(e[-1] / e[-2]):      # a remainder narrower than half the last bin
+        e.pop()
+    return np.array(e + [float(k_max)])
+
+
+def concept_power_table(pos, boxsize: float, ngrid: int, pk_table=None, growth: float = 1.0, noise_power=None, nbins: Optional[int] = None,
+                        bins_per_decade=None, k_max: Optional[float] = None, interlace: bool = True, deconvolve: bool = True):
     """The columns of a CONCEPT power-spectrum file (PPPMP3M/PP/powerspec/powerspec_a=1.00:10-26; read back by
     pppmp3mplotter.py:123-134 and Power_compare.py:625-629 with usecols (0, 2, 3, 4)):
         k (mean |k| of the bin), modes (independent half-space modes), P, P corrected, P linear
     P from the CIC-deposited, deconvolved, interlaced field (`power_modes`, the settings of NN.param:28-45) in linear |k| bins of
-    width 2 k_fundamental up to the Nyquist frequency. `P linear` = growth^2 x the tabulated linear spectrum averaged over the bin's
+    width 2 k_fundamental up to the Nyquist frequency — or, with `bins_per_decade` (the parsed powerspec_options['bins per decade']), in
+    the logarithmic bins of `bins_per_decade_edges` up to `k_max`. `P linear` = growth^2 x the tabulated linear spectrum averaged over the bin's
     modes; `P corrected` = P x sum(P_lin) / sum(P_lin |R_k|^2) — CONCEPT's 'realization correction', which removes the cosmic
     variance of the initial noise R from the estimate (nan columns when no table / noise is given)."""
-    k, p = power_modes(pos, boxsize, ngrid, interlace=True)
+    k, p = power_modes(pos, boxsize, ngrid, interlace=interlace, deconvolve=deconvolve)
     kf = 2 * np.pi / boxsize
-    kny = np.pi * ngrid / boxsize
-    nb = int(nbins) if nbins else max(1, int(np.ceil((kny - 0.5 * kf) / (2 * kf))))
-    edges = np.linspace(0.5 * kf, kny, nb + 1)
+    kny = np.pi * ngrid / boxsize if k_max is None else float(k_max)
+    if bins_per_decade is not None:          # powerspec_options['bins per decade'] of the parameter file
+        edges = bins_per_decade_edges(bins_per_decade, kf, kny)
+        edges[-1] *= 1.0 + 1e-12             # the modes AT k_max belong to the last bin
+        nb = len(edges) - 1
+    else:
+        nb = int(nbins) if nbins else max(1, int(np.ceil((kny - 0.5 * kf) / (2 * kf))))
+        edges = np.linspace(0.5 * kf, kny, nb + 1)
     which = np.digitize(k, edges) - 1
     ok = (which >= 0) & (which < nb)
     cnt = np.bincount(which[ok], minlength=nb)
@@ -322,7 +350,7 @@ def run_rungs(pos, vel, mass: float, boxsize: float, cosmo: Cosmology, a_begin: 
     return out + (np.array(pops),) if return_populations else out
 
 
-def power_modes(pos, boxsize: float, ngrid: int, interlace: bool = True):
+def power_modes(pos, boxsize: float, ngrid: int, interlace: bool = True, deconvolve: bool = True):
     """Per-mode (|k|, P) of the CIC-deposited, window-deconvolved overdensity, optionally INTERLACED (two grids half a
     cell apart combined in k-space, which cancels the odd aliases) — CONCEPT's estimator settings in NN.param:30-41
     ('interpolation': 'CIC', 'deconvolve': True, 'interlace': True). The thesis' own estimator (Power_compare.py) does not
@@ -334,6 +362,9 @@ def power_modes(pos, boxsize: float, ngrid: int, interlace: bool = True):
     kv = 2 * np.pi * np.fft.fftfreq(ngrid, d=boxsize / ngrid)
     k2 = kv * kv
     kmag = np.sqrt(k2[:, None, None] + k2[None, :, None] + k2[None, None, :])
+    if not deconvolve:                       # powerspec_options['deconvolve'] = False: put the CIC window (sinc^2 per axis, squared for power) back
+        w = np.sinc(kv * (boxsize / ngrid) / (2 * np.pi)) ** 2
+        pk = pk * (w[:, None, None] * w[None, :, None] * w[None, None, :]) ** 2
     sel = kmag > 0
     return kmag[sel], pk[sel]
 

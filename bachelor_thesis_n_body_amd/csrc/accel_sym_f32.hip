@@ -45,18 +45,41 @@ template <bool UNIFORM> __device__ inline float4 ld_src(const float4* p) {
   return *p;
 }
 
-// Offsets of this launch are numbered o = 0 .. : o = 0 -> d = 0 (one-sided), o = 1 .. H -> d = o (two-sided), o = H + 1 -> d = nsets / 2
-// (one-sided; only when nsets is even). A launch covers the offsets [o_begin, o_end); its (offset, tile) pairs are dealt to the groups y.
+// ---- the work of a launch and how it is dealt to the blocks -------------------------------------------------------------------------
+// Offsets of a launch are numbered o = 0 .. : o = 0 -> d = 0 (one-sided), o = 1 .. H -> d = o (two-sided), o = H + 1 -> d = nsets / 2
+// (one-sided; only when nsets is even); a launch covers the offsets [o_begin, o_end) for the sink sets b0 .. b0 + nb_sets - 1. Its work is
+// the sequence of STEPS  g = ((bb * tps + tau) * HS + t):  sink set bb of the launch, tile tau = (o - o_begin) * QT + q of its tps tiles,
+// step t of the HS = TJ / U steps of a tile — G steps in all, every step the same amount of work (KS * U pair terms per lane).
+// Block k of B takes the steps [part_begin(k), part_begin(k + 1)): equal shares to within one pair of steps, whatever the set and tile
+// counts are. (Round 3 dealt whole runs of tiles to a (set, group) grid: 342 x 12 = 4104 equal blocks on 512 resident slots at N = 2^20 is
+// 8.02 rounds — the ninth, with 8 blocks, cost 6 % of the launch; at N = 65 536, 2176 one-tile blocks = 4.25 rounds cost 15 %.)
+// A block walks its tiles in order; when the sink set changes it stores the set's sink sums to slot (ordinal of this block among the blocks
+// that share the set) of the fp64 `part` slab and loads the next set. A tile cut by a block boundary is walked by two blocks: the one that
+// holds its step 0 writes the tile's source sums to the regular slab slot, the other to its own row of the `bslab`, which a small kernel adds
+// afterwards (B <= G / HS, so a tile is cut at most once). All of it is a fixed function of (n, B): bit-reproducible.
+__host__ __device__ inline long long part_begin(long long k, long long G, int B) { return k >= B ? G : ((k * G / B) & ~1LL); }
+__host__ __device__ inline int part_block_of(long long s, long long G, int B) {       // the block whose range holds step s
+  int k = (int)(s * B / G);
+  if (k > B - 1) k = B - 1;
+  if (k + 1 < B && part_begin(k + 1, G, B) <= s) ++k;
+  return k;
+}
+// set met by sink set b at offset o
+__device__ inline int sym_set_of(int b, int o, int cross, int nsets, int nsets_src, int H) {
+  if (cross) return (b + o) % nsets_src;
+  const int d = o <= H ? o : nsets / 2; const int c = b + d; return c >= nsets ? c - nsets : c;
+}
+
 template <int KS, int U, int TJ, bool GUARD, bool UNIFORM, bool POT>
 __global__ void __launch_bounds__(BLOCK)
 accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ m,
-                     int n, int nsets, int H, int o_begin, int o_end, int t_per_group, float eps2,
-                     double* __restrict__ part, float* __restrict__ slab, size_t n_pad,
+                     int n, int nsets, int H, int o_begin, int tps, long long G, float eps2,
+                     double* __restrict__ part, float* __restrict__ slab, float* __restrict__ bslab, size_t n_pad,
                      const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs, const float* __restrict__ ms,
                      int n_src, int nsets_src, size_t n_pad_src, int cross, int b0) {
   // cross = 0: the set (x, y, z, m) on itself (xs.. are the same arrays). cross = 1: block A = (x..) against a DIFFERENT block B = (xs..):
   // sink set b of A walks every set of B two-sidedly (o = 0 .. nsets_src - 1 -> set (b + o) mod nsets_src); B's sums go to slab slot
-  // blockIdx.x (one slot per sink set of this launch, which covers the sink sets b0 .. b0 + gridDim.x - 1).
+  // b - b0 (one slot per sink set of this launch).
   static_assert(KS % 2 == 0 && TJ % BLOCK == 0 && TJ % U == 0, "shape");
   constexpr int NC = POT ? 4 : 3;    // POT: the pair potential m / sqrt(r^2 + eps^2) rides along as a fourth component on both sides
   constexpr int SET = BLOCK * KS;
@@ -64,50 +87,58 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
   constexpr int AS = TJ + 64;        // tile entries incl. the 64 wrap-around copies
   constexpr int LPT = TJ / BLOCK;
   constexpr int QT = SET / TJ;       // tiles per set
+  constexpr int HS = TJ / U;         // steps per tile
+  static_assert(HS % 2 == 0, "steps are taken in pairs");
   __shared__ float4 tile[AS];
   constexpr int AW = 2;              // the two halves of a packed partial sum keep separate accumulators (no add per step)
   __shared__ float acc[WAVES][NC][AS * AW];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int b = b0 + blockIdx.x;
-  const int i0 = b * SET + tid;
   const float far = 1e20f;           // UNIFORM padding: r^2 overflows to +inf, v_rsq_f32(+inf) = +0, every term exactly 0
+  const int nblk = gridDim.x, kb = blockIdx.x;
+  const long long g_begin = part_begin(kb, G, nblk), g_end = part_begin(kb + 1, G, nblk);
+  const long long S = (long long)tps * HS;                 // steps per sink set
 
   v2f px[KP], py[KP], pz[KP], pm[KP];
-#pragma unroll
-  for (int p = 0; p < KP; ++p) {
-    const int ia = i0 + (2 * p) * BLOCK, ib = ia + BLOCK;
-    const bool oa = ia < n, ob = ib < n;
-    const int ca = oa ? ia : n - 1, cb = ob ? ib : n - 1;
-    if (UNIFORM) {
-      px[p] = v2f{oa ? x[ca] : far, ob ? x[cb] : far}; py[p] = v2f{oa ? y[ca] : far, ob ? y[cb] : far}; pz[p] = v2f{oa ? z[ca] : far, ob ? z[cb] : far};
-      pm[p] = v2f{0.f, 0.f};
-    } else {                         // padded sinks: a real position with zero mass (they push nothing onto the sources)
-      px[p] = v2f{x[ca], x[cb]}; py[p] = v2f{y[ca], y[cb]}; pz[p] = v2f{z[ca], z[cb]};
-      pm[p] = v2f{oa ? m[ca] : 0.f, ob ? m[cb] : 0.f};
-    }
-  }
   double tx[KS], ty[KS], tz[KS], tp[KS];
+  auto load_sinks = [&](int b) {
+    const int i0 = b * SET + tid;
 #pragma unroll
-  for (int k = 0; k < KS; ++k) { tx[k] = 0.0; ty[k] = 0.0; tz[k] = 0.0; tp[k] = 0.0; }
+    for (int p = 0; p < KP; ++p) {
+      const int ia = i0 + (2 * p) * BLOCK, ib = ia + BLOCK;
+      const bool oa = ia < n, ob = ib < n;
+      const int ca = oa ? ia : n - 1, cb = ob ? ib : n - 1;
+      if (UNIFORM) {
+        px[p] = v2f{oa ? x[ca] : far, ob ? x[cb] : far}; py[p] = v2f{oa ? y[ca] : far, ob ? y[cb] : far}; pz[p] = v2f{oa ? z[ca] : far, ob ? z[cb] : far};
+        pm[p] = v2f{0.f, 0.f};
+      } else {                       // padded sinks: a real position with zero mass (they push nothing onto the sources)
+        px[p] = v2f{x[ca], x[cb]}; py[p] = v2f{y[ca], y[cb]}; pz[p] = v2f{z[ca], z[cb]};
+        pm[p] = v2f{oa ? m[ca] : 0.f, ob ? m[cb] : 0.f};
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) { tx[k] = 0.0; ty[k] = 0.0; tz[k] = 0.0; tp[k] = 0.0; }
+#pragma unroll
+    for (int p = 0; p < KP; ++p) asm volatile("" : "+v"(px[p]), "+v"(py[p]), "+v"(pz[p]), "+v"(pm[p]));
+  };
+  auto store_sinks = [&](int b, int seg) {                 // the set's sink sums of this block: slot `seg` of the part slab
+    double* pp = part + (size_t)seg * NC * n_pad;
+    const int i0 = b * SET + tid;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int i = i0 + k * BLOCK;
+      if (i < n) { pp[i] = tx[k]; pp[n_pad + i] = ty[k]; pp[2 * n_pad + i] = tz[k]; if (POT) pp[3 * n_pad + i] = tp[k]; }
+    }
+  };
   v2f e2;
   asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2" : "=v"(e2.x), "=v"(e2.y) : "s"(eps2));
 
   for (int e = tid; e < WAVES * NC * AS * AW; e += BLOCK) (&acc[0][0][0])[e] = 0.f;
 
-  // the (offset, tile of the set) pairs of this launch, o_begin * QT .. o_end * QT, are dealt to the groups y in runs of t_per_group
-  const int t_lo = o_begin * QT + blockIdx.y * t_per_group;
-  const int t_hi = min(o_end * QT, t_lo + t_per_group);
-  const int ntiles = max(0, t_hi - t_lo);
-
-  auto set_of = [&](int o) {
-    if (cross) return (b + o) % nsets_src;
-    const int d = o <= H ? o : nsets / 2; int c = b + d; return c >= nsets ? c - nsets : c;
-  };
-
   float4 stage[LPT];
-  auto fetch = [&](int T) {
-    const int c = set_of((t_lo + T) / QT), q = (t_lo + T) % QT;
+  auto fetch = [&](long long tile_id) {                    // sources of tile `tile_id` of the launch into registers
+    const int bb = (int)(tile_id / tps), tau = (int)(tile_id - (long long)bb * tps);
+    const int c = sym_set_of(b0 + bb, o_begin + tau / QT, cross, nsets, nsets_src, H), q = tau % QT;
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
       const int j = c * SET + q * TJ + l * BLOCK + tid;
@@ -123,15 +154,13 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
     if (tid < 64) tile[TJ + tid] = stage[0];       // wrap-around copies of entries 0..63
   };
 
-  if (ntiles > 0) { fetch(0); commit(); }
-#pragma unroll
-  for (int p = 0; p < KP; ++p) asm volatile("" : "+v"(px[p]), "+v"(py[p]), "+v"(pz[p]), "+v"(pm[p]));
+  if (g_begin < g_end) { fetch(g_begin / HS); commit(); }
   __syncthreads();
 
   const float4* tl = tile + lane;
   float* ac = &acc[wv][0][lane * AW];
 
-  auto walk = [&](auto symtag) {
+  auto walk = [&](auto symtag, int t_lo, int t_hi) {
     constexpr bool SYM = decltype(symtag)::value;
     v2f fx[KP], fy[KP], fz[KP], fp[KP];
 #pragma unroll
@@ -140,7 +169,6 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
     // The sources of step t + 1 are read during step t into the other of two register sets (the tile has 64 entries beyond the last
     // step's); the accumulators of a step are read at its top and consumed at its end (the scheduler may not pull the source-side
     // chains above the sink-side work), so no LDS round trip is exposed.
-    constexpr int HS = TJ / U;
     auto step = [&](float4 (&s)[U], float4 (&nx)[U], int t) {
       v2f gx[U], gy[U], gz[U], gp[U];
       // lane l reads the accumulator lane l + 1 wrote one step earlier (same wave: LDS operations complete in program order); the
@@ -220,9 +248,8 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
     };
     float4 sa[U], sb[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) sa[u] = ld_src<UNIFORM>(tl + u * HS);
-    static_assert(HS % 2 == 0, "steps are taken in pairs");
-    for (int t = 0; t < HS; t += 2) { step(sa, sb, t); step(sb, sa, t + 1); }
+    for (int u = 0; u < U; ++u) sa[u] = ld_src<UNIFORM>(tl + t_lo + u * HS);
+    for (int t = t_lo; t < t_hi; t += 2) { step(sa, sb, t); step(sb, sa, t + 1); }
 #pragma unroll
     for (int p = 0; p < KP; ++p) {
       tx[2 * p] += (double)fx[p].x; ty[2 * p] += (double)fy[p].x; tz[2 * p] += (double)fz[p].x;
@@ -231,15 +258,30 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
     }
   };
 
-  for (int T = 0; T < ntiles; ++T) {
-    const int o = (t_lo + T) / QT, q = (t_lo + T) % QT;
+  int cur = -1, seg = 0;                                   // sink set (of the launch) in registers, and this block's slot among the set's blocks
+  for (long long g = g_begin; g < g_end;) {
+    const long long tile_id = g / HS;
+    const int t_lo = (int)(g - tile_id * HS);
+    const int t_hi = (int)((long long)HS < t_lo + (g_end - g) ? (long long)HS : t_lo + (g_end - g));
+    const int bb = (int)(tile_id / tps), tau = (int)(tile_id - (long long)bb * tps);
+    const int o = o_begin + tau / QT, q = tau % QT;
     const bool sym = cross || (o >= 1 && o <= H);
-    if (T + 1 < ntiles) fetch(T + 1);
-    if (sym) walk(std::true_type{}); else walk(std::false_type{});
+    if (bb != cur) {
+      if (cur >= 0) store_sinks(b0 + cur, seg);
+      seg = cur < 0 ? kb - part_block_of((long long)bb * S, G, nblk) : 0;     // a set that begins inside this block's range: its first block
+      cur = bb;
+      load_sinks(b0 + bb);
+    }
+    const long long g_next = g + (t_hi - t_lo);
+    if (g_next < g_end) fetch(g_next / HS);
+    if (sym) walk(std::true_type{}, t_lo, t_hi); else walk(std::false_type{}, t_lo, t_hi);
     __syncthreads();                                   // every wave has finished the tile: accumulators complete, tile free
     if (sym) {
-      const int c = set_of(o);
-      float* sl = slab + (size_t)(cross ? (int)blockIdx.x : o - max(o_begin, 1)) * NC * n_pad_src + (size_t)c * SET + (size_t)q * TJ;
+      const int c = sym_set_of(b0 + bb, o, cross, nsets, nsets_src, H);
+      // the block that holds step 0 of a tile owns its slab entry; a block that starts inside the tile leaves its share in its bslab row
+      float* sl = t_lo == 0 ? slab + (size_t)(cross ? bb : o - max(o_begin, 1)) * NC * n_pad_src + (size_t)c * SET + (size_t)q * TJ
+                            : bslab + (size_t)kb * NC * TJ;
+      const size_t cstride = t_lo == 0 ? n_pad_src : (size_t)TJ;
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc)
         for (int e = tid; e < TJ; e += BLOCK) {
@@ -254,36 +296,58 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
 #pragma unroll
               for (int h = 0; h < AW; ++h) { v += acc[w2][cc][(TJ + e) * AW + h]; acc[w2][cc][(TJ + e) * AW + h] = 0.f; }
           }
-          sl[(size_t)cc * n_pad_src + e] = v;
+          sl[(size_t)cc * cstride + e] = v;
         }
     }
-    if (T + 1 < ntiles) commit();
+    if (g_next < g_end) commit();
     __syncthreads();
+    g = g_next;
   }
-
-  double* pp = part + (size_t)blockIdx.y * NC * n_pad;
-#pragma unroll
-  for (int k = 0; k < KS; ++k) {
-    const int i = i0 + k * BLOCK;
-    if (i < n) { pp[i] = tx[k]; pp[n_pad + i] = ty[k]; pp[2 * n_pad + i] = tz[k]; if (POT) pp[3 * n_pad + i] = tp[k]; }
-  }
+  if (cur >= 0) store_sinks(b0 + cur, seg);
 }
 
-// a[c][i] (+)= g * ( sum_y part[y][c][i] + sum_s slab[s][c][i] ), fixed order; `tot` non-null: the sums of several passes are collected in
-// fp64 first (first: tot = sum, otherwise tot += sum) and turned into accelerations by the last pass
+// slab entry of a tile cut by a block boundary += the share of the block that started inside it (one such block per tile: B <= G / HS)
+template <int KS, int U, int TJ, bool POT>
+__global__ void __launch_bounds__(BLOCK)
+accel_sym_boundary_f32_kernel(float* __restrict__ slab, const float* __restrict__ bslab, int nsets, int H, int o_begin, int tps, long long G,
+                              int nsets_src, size_t n_pad_src, int cross, int b0) {
+  constexpr int NC = POT ? 4 : 3, SET = BLOCK * KS, QT = SET / TJ, HS = TJ / U;
+  const int kb = blockIdx.x, nblk = gridDim.x;
+  const long long g = part_begin(kb, G, nblk);
+  if (g >= part_begin(kb + 1, G, nblk)) return;
+  const long long tile_id = g / HS;
+  if (g == tile_id * HS) return;                           // starts on a tile boundary: owns its first tile
+  const int bb = (int)(tile_id / tps), tau = (int)(tile_id - (long long)bb * tps);
+  const int o = o_begin + tau / QT, q = tau % QT;
+  if (!(cross || (o >= 1 && o <= H))) return;              // one-sided tiles have no source sums
+  const int c = sym_set_of(b0 + bb, o, cross, nsets, nsets_src, H);
+  float* sl = slab + (size_t)(cross ? bb : o - max(o_begin, 1)) * NC * n_pad_src + (size_t)c * SET + (size_t)q * TJ;
+  const float* bs = bslab + (size_t)kb * NC * TJ;
+  for (int cc = 0; cc < NC; ++cc)
+    for (int e = threadIdx.x; e < TJ; e += BLOCK) sl[(size_t)cc * n_pad_src + e] += bs[cc * TJ + e];
+}
+
+// a[c][i] (+)= g * ( sum_seg part[seg][c][i] + sum_s slab[s][c][i] ), fixed order; `tot` non-null: the sums of several passes are collected in
+// fp64 first (first: tot = sum, otherwise tot += sum) and turned into accelerations by the last pass. The part slots of a particle are those of
+// the blocks that shared its sink set (part_block_of: the same function of (G, nblk) the force kernel dealt its work by); nblk = 0: no part slab.
 __global__ void __launch_bounds__(256)
-accel_sym_reduce_f32_kernel(const double* __restrict__ part, int ngroups, const float* __restrict__ slab, int nslots, int n, size_t n_pad,
-                            float G, const float* __restrict__ m0, double* __restrict__ tot, int first, int last,
+accel_sym_reduce_f32_kernel(const double* __restrict__ part, long long G, int nblk, long long S, int set_size, int b0,
+                            const float* __restrict__ slab, int nslots, int n, size_t n_pad,
+                            float G_newton, const float* __restrict__ m0, double* __restrict__ tot, int first, int last,
                             float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, int accumulate, double* __restrict__ phi,
                             int i_begin) {
   const int nc = phi ? 4 : 3;
   const int i = i_begin + blockIdx.x * blockDim.x + threadIdx.x;      // particles [i_begin, n)
   if (i >= n) return;
   double sx = 0.0, sy = 0.0, sz = 0.0, sp = 0.0;
-  for (int g = 0; g < ngroups; ++g) {
-    const double* p = part + (size_t)g * nc * n_pad;
-    sx += p[i]; sy += p[n_pad + i]; sz += p[2 * n_pad + i];
-    if (phi) sp += p[3 * n_pad + i];
+  if (nblk > 0) {
+    const long long bb = i / set_size - b0;
+    const int nseg = part_block_of((bb + 1) * S - 1, G, nblk) - part_block_of(bb * S, G, nblk) + 1;
+    for (int g = 0; g < nseg; ++g) {
+      const double* p = part + (size_t)g * nc * n_pad;
+      sx += p[i]; sy += p[n_pad + i]; sz += p[2 * n_pad + i];
+      if (phi) sp += p[3 * n_pad + i];
+    }
   }
 #pragma unroll 8
   for (int s = 0; s < nslots; ++s) {
@@ -296,7 +360,7 @@ accel_sym_reduce_f32_kernel(const double* __restrict__ part, int ngroups, const 
     if (!last) { tot[i] = sx; tot[(size_t)n + i] = sy; tot[2 * (size_t)n + i] = sz; if (phi) tot[3 * (size_t)n + i] = sp; return; }
   }
   if (phi) { const double ph = (m0 ? (double)m0[0] : 1.0) * sp; phi[i] = accumulate ? phi[i] + ph : ph; }   // per unit G, self term included
-  const double g = m0 ? (double)G * (double)m0[0] : (double)G;
+  const double g = m0 ? (double)G_newton * (double)m0[0] : (double)G_newton;
   float ox = (float)(g * sx), oy = (float)(g * sy), oz = (float)(g * sz);
   if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
   ax[i] = ox; ay[i] = oy; az[i] = oz;
@@ -307,10 +371,34 @@ long long env_ll(const char* name, long long dflt) {
   return v && *v ? atoll(v) : dflt;
 }
 
+// Blocks of a launch: the resident block slots of the device for this kernel (occupancy x CUs) times `rounds` (NB_F32_SYM_ROUNDS, default 1:
+// every block resident at once, equal shares — any multiple stays balanced because shares are equal to a step), never more than one block
+// per tile (a tile may be cut once only), NB_F32_SYM_BLOCKS overrides.
+template <typename K>
+int sym_blocks(nb_ctx* c, K kernel, long long tiles, long long env_blocks, long long env_rounds) {
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
+  long long nblk = env_blocks > 0 ? env_blocks : (long long)per_cu * cus * std::max<long long>(1, env_rounds);
+  if (nblk > tiles) nblk = tiles;
+  if (nblk > 65535 * 16) nblk = 65535 * 16;
+  return (int)std::max<long long>(1, nblk);
+}
+
+// the instantiation for (coincident-pair guard, equal masses). 12 sinks per lane exist for equal masses only (per-particle masses would need
+// 256 VGPRs): there the per-particle-mass slot names the equal-mass kernel again, so that it is never instantiated (callers pass uniform = true)
+template <int KS, int U, int TJ, bool POT>
+auto sym_kernel(bool guard, bool uniform) {
+  constexpr bool ONLY_UNIFORM = KS == 12;
+  if (guard) return uniform ? accel_sym_f32_kernel<KS, U, TJ, true, true, POT> : accel_sym_f32_kernel<KS, U, TJ, true, ONLY_UNIFORM, POT>;
+  return uniform ? accel_sym_f32_kernel<KS, U, TJ, false, true, POT> : accel_sym_f32_kernel<KS, U, TJ, false, ONLY_UNIFORM, POT>;
+}
+
 template <int KS, int U, bool POT>
 int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
-            float eps2, float G, float* ax, float* ay, float* az, int flags, long long budget, long long env_groups, double* phi) {
+            float eps2, float G, float* ax, float* ay, float* az, int flags, long long budget, long long env_blocks, long long env_rounds, double* phi) {
   constexpr int TJ = POT ? 256 : 512, SET = BLOCK * KS, NC = POT ? 4 : 3;   // POT: a fourth accumulator per source — half the tile keeps the LDS footprint
+  constexpr int QT = SET / TJ, HS = TJ / U;                  // tiles per set, steps per tile
   const int nsets = (int)((n + SET - 1) / SET);
   const size_t n_pad = (size_t)nsets * SET;
   const int H = (nsets - 1) / 2;
@@ -318,52 +406,50 @@ int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const flo
   const size_t slot_bytes = NC * n_pad * sizeof(float);
   // clamped in 64 bits BEFORE the cast: a budget meant as "unlimited" (INT64_MAX) must not wrap
   int slots_per_pass = (int)std::min<long long>(std::max<long long>(1, budget / (long long)slot_bytes), (long long)std::max(H, 1));
-  // pass 0 takes o = 0 and the first two-sided offsets, the last pass also the one-sided half offset
-  constexpr int QT = SET / TJ;                               // tiles per set
-  // groups: ~4096 blocks PER PASS (see accel_f32.hip's split sweep; a pass of a large problem must not shrink to a round or two of blocks)
-  int groups_target = env_groups > 0 ? (int)env_groups : (4096 + nsets - 1) / nsets;
-  if (groups_target < 1) groups_target = 1;
-  const int max_groups_pass = groups_target + 1;
-  const size_t part_bytes = (size_t)max_groups_pass * NC * n_pad * sizeof(double);
-  int npass;
-  size_t slab_bytes, tot_bytes;
+  const bool uniform = (flags & NB_UNIFORM_MASS) != 0;
+  const bool guard = !(eps2 >= 1e-20f);
+  const int accumulate = flags & NB_ACCUMULATE;
+  // the kernel instantiation of this call (for the occupancy query and the launches)
+  const auto kernel = sym_kernel<KS, U, TJ, POT>(guard, uniform);
+  // pass 0 takes o = 0 and the first two-sided offsets, the last pass also the one-sided half offset. The blocks of the LARGEST pass size the
+  // scratch: part slab [blocks sharing a set + 1][NC][n_pad] fp64, boundary slab [blocks][NC][TJ].
+  int npass, nblk_max, nseg_max;
+  size_t part_bytes, bslab_bytes, slab_bytes, tot_bytes;
   for (;;) {                                                 // the allocator may refuse the scratch: fewer slots per pass, then give up (one-sided kernel)
     npass = H > 0 ? (H + slots_per_pass - 1) / slots_per_pass : 1;
+    const long long tiles_max = (long long)nsets * std::min(n_o, slots_per_pass + 2) * QT;
+    nblk_max = sym_blocks(c, kernel, tiles_max, env_blocks, env_rounds);
+    nseg_max = nblk_max / nsets + 2;
+    part_bytes = (size_t)nseg_max * NC * n_pad * sizeof(double);
+    bslab_bytes = (size_t)nblk_max * NC * TJ * sizeof(float);
     slab_bytes = (size_t)slots_per_pass * slot_bytes;
     tot_bytes = npass > 1 ? NC * (size_t)n * sizeof(double) : 0;
-    const int rc = nb_try_ensure_work(c, part_bytes + slab_bytes + tot_bytes, c->sym_scratch_limit);
+    const int rc = nb_try_ensure_work(c, part_bytes + bslab_bytes + slab_bytes + tot_bytes, c->sym_scratch_limit);
     if (rc == NB_OK) break;
     if (rc != NB_WORK_UNAVAILABLE || slots_per_pass <= 1) return rc;
     slots_per_pass = (slots_per_pass + 1) / 2;
   }
-  double* part = reinterpret_cast<double*>(c->work);
-  float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(c->work) + part_bytes);
-  double* tot = npass > 1 ? reinterpret_cast<double*>(reinterpret_cast<char*>(c->work) + part_bytes + slab_bytes) : nullptr;
-  const bool uniform = (flags & NB_UNIFORM_MASS) != 0;
-  const bool guard = !(eps2 >= 1e-20f);
-  const int accumulate = flags & NB_ACCUMULATE;
+  char* w = reinterpret_cast<char*>(c->work);
+  double* part = reinterpret_cast<double*>(w);
+  float* bslab = reinterpret_cast<float*>(w + part_bytes);
+  float* slab = reinterpret_cast<float*>(w + part_bytes + bslab_bytes);
+  double* tot = npass > 1 ? reinterpret_cast<double*>(w + part_bytes + bslab_bytes + slab_bytes) : nullptr;
   for (int ps = 0; ps < npass; ++ps) {
     // two-sided offsets of this pass: o in [1 + ps * spp, 1 + min(H, (ps + 1) * spp)); o = 0 rides with pass 0, o = H + 1 with the last
     const int s_begin = 1 + ps * slots_per_pass, s_end = 1 + std::min(H, (ps + 1) * slots_per_pass);
     const int o_begin = ps == 0 ? 0 : s_begin;
     const int o_end = (ps == npass - 1) ? n_o : s_end;
-    const int pass_tiles = (o_end - o_begin) * QT;             // (offset, tile) pairs of this pass, dealt to the groups in runs of tpg
-    const int tpg = std::max(1, (pass_tiles + groups_target - 1) / groups_target);
-    const int ngroups = (pass_tiles + tpg - 1) / tpg;
+    const int tps = (o_end - o_begin) * QT;                   // tiles per sink set in this pass
+    const long long Gs = (long long)nsets * tps * HS;        // steps of this pass
+    const int nblk = std::min(nblk_max, sym_blocks(c, kernel, (long long)nsets * tps, env_blocks, env_rounds));
     const int nslots = std::max(0, s_end - s_begin);
-    if (ngroups > max_groups_pass) return nb_fail(c, NB_ERR_ARG, "accel_sym_f32: internal group count");
-    dim3 grid(nsets, ngroups);
-#define NB_SYM_GO(GD, UF) accel_sym_f32_kernel<KS, U, TJ, GD, UF, POT><<<grid, BLOCK, 0, c->stream>>>( \
-    x, y, z, m, (int)n, nsets, H, o_begin, o_end, tpg, eps2, part, slab, n_pad, x, y, z, m, (int)n, nsets, n_pad, 0, 0)
-    if constexpr (KS == 12) {            // equal masses only
-      if (guard) NB_SYM_GO(true, true); else NB_SYM_GO(false, true);
-    } else {
-      if (guard) { if (uniform) NB_SYM_GO(true, true); else NB_SYM_GO(true, false); }
-      else       { if (uniform) NB_SYM_GO(false, true); else NB_SYM_GO(false, false); }
-    }
-#undef NB_SYM_GO
+    if (nblk / nsets + 2 > nseg_max) return nb_fail(c, NB_ERR_ARG, "accel_sym_f32: internal slot count");
+    kernel<<<nblk, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, nsets, H, o_begin, tps, Gs, eps2, part, slab, bslab, n_pad,
+                                          x, y, z, m, (int)n, nsets, n_pad, 0, 0);
     NB_HIP(c, hipGetLastError());
-    accel_sym_reduce_f32_kernel<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(part, ngroups, slab, nslots, (int)n, n_pad, G,
+    accel_sym_boundary_f32_kernel<KS, U, TJ, POT><<<nblk, BLOCK, 0, c->stream>>>(slab, bslab, nsets, H, o_begin, tps, Gs, nsets, n_pad, 0, 0);
+    NB_HIP(c, hipGetLastError());
+    accel_sym_reduce_f32_kernel<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(part, Gs, nblk, (long long)tps * HS, SET, 0, slab, nslots, (int)n, n_pad, G,
                                                                                  uniform ? m : nullptr, tot, ps == 0, ps == npass - 1,
                                                                                  ax, ay, az, accumulate, phi, 0);
     NB_HIP(c, hipGetLastError());
@@ -377,51 +463,53 @@ template <int KS, int U, bool POT>
 int run_cross(nb_ctx* c, const float* xa, const float* ya, const float* za, const float* ma, int64_t na,
               const float* xb, const float* yb, const float* zb, const float* mb, int64_t nb,
               float eps2, float G, float* aax, float* aay, float* aaz, float* bax, float* bay, float* baz,
-              double* phi_a, double* phi_b, int flags, long long budget) {
+              double* phi_a, double* phi_b, int flags, long long budget, long long env_blocks, long long env_rounds) {
   constexpr int TJ = POT ? 256 : 512, SET = BLOCK * KS, NC = POT ? 4 : 3;
+  constexpr int QT = SET / TJ, HS = TJ / U;
   const int nsa = (int)((na + SET - 1) / SET), nsb = (int)((nb + SET - 1) / SET);
   const size_t npa = (size_t)nsa * SET, npb = (size_t)nsb * SET;
   const size_t slot_bytes = NC * npb * sizeof(float);
   int sets_per_pass = (int)std::min<long long>(std::max<long long>(1, budget / (long long)slot_bytes), (long long)std::max(nsa, 1));
-  constexpr int QT = SET / TJ;
-  int groups, tpg;
-  size_t part_bytes;
+  const bool uniform = (flags & NB_UNIFORM_MASS) != 0;
+  const bool guard = !(eps2 >= 1e-20f);
+  const auto kernel = sym_kernel<KS, U, TJ, POT>(guard, uniform);
+  const int tps = nsb * QT;                                   // every set of B, tile by tile
+  int nblk_max, nseg_max;
+  size_t part_bytes, bslab_bytes;
   for (;;) {                                                 // as run_sym: fewer sets of A per pass if the allocator refuses, then give up
-    groups = (4096 + sets_per_pass - 1) / sets_per_pass;                    // ~4096 blocks per launch
-    if (groups > nsb * QT) groups = nsb * QT;
-    if (groups < 1) groups = 1;
-    tpg = (nsb * QT + groups - 1) / groups;                                 // (set of B, tile) pairs per group
-    groups = (nsb * QT + tpg - 1) / tpg;
-    part_bytes = (size_t)groups * NC * npa * sizeof(double);
-    const int rc = nb_try_ensure_work(c, part_bytes + (size_t)sets_per_pass * slot_bytes, c->sym_scratch_limit);
+    nblk_max = sym_blocks(c, kernel, (long long)sets_per_pass * tps, env_blocks, env_rounds);
+    nseg_max = nblk_max / sets_per_pass + 2;                 // blocks that can share one sink set (+ the two cut ends)
+    const int rest = nsa % sets_per_pass;                    // a last pass with fewer sets shares its blocks among fewer sets
+    if (rest > 0) nseg_max = std::max(nseg_max, sym_blocks(c, kernel, (long long)rest * tps, env_blocks, env_rounds) / rest + 2);
+    part_bytes = (size_t)nseg_max * NC * npa * sizeof(double);
+    bslab_bytes = (size_t)nblk_max * NC * TJ * sizeof(float);
+    const int rc = nb_try_ensure_work(c, part_bytes + bslab_bytes + (size_t)sets_per_pass * slot_bytes, c->sym_scratch_limit);
     if (rc == NB_OK) break;
     if (rc != NB_WORK_UNAVAILABLE || sets_per_pass <= 1) return rc;
     sets_per_pass = (sets_per_pass + 1) / 2;
   }
-  double* part = reinterpret_cast<double*>(c->work);
-  float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(c->work) + part_bytes);
-  const bool uniform = (flags & NB_UNIFORM_MASS) != 0;
-  const bool guard = !(eps2 >= 1e-20f);
+  char* w = reinterpret_cast<char*>(c->work);
+  double* part = reinterpret_cast<double*>(w);
+  float* bslab = reinterpret_cast<float*>(w + part_bytes);
+  float* slab = reinterpret_cast<float*>(w + part_bytes + bslab_bytes);
   for (int b0 = 0; b0 < nsa; b0 += sets_per_pass) {
     const int nb_sets = std::min(sets_per_pass, nsa - b0);
-    dim3 grid(nb_sets, groups);
-#define NB_SYM_GO(GD, UF) accel_sym_f32_kernel<KS, U, TJ, GD, UF, POT><<<grid, BLOCK, 0, c->stream>>>( \
-    xa, ya, za, ma, (int)na, nsa, 0, 0, nsb, tpg, eps2, part, slab, npa, xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0)
-    if constexpr (KS == 12) {
-      if (guard) NB_SYM_GO(true, true); else NB_SYM_GO(false, true);
-    } else {
-      if (guard) { if (uniform) NB_SYM_GO(true, true); else NB_SYM_GO(true, false); }
-      else       { if (uniform) NB_SYM_GO(false, true); else NB_SYM_GO(false, false); }
-    }
-#undef NB_SYM_GO
+    const long long Gs = (long long)nb_sets * tps * HS;
+    const int nb_launch = std::min(nblk_max, sym_blocks(c, kernel, (long long)nb_sets * tps, env_blocks, env_rounds));
+    if (nb_launch / nb_sets + 2 > nseg_max) return nb_fail(c, NB_ERR_ARG, "accel_sym_f32: internal slot count");
+    kernel<<<nb_launch, BLOCK, 0, c->stream>>>(xa, ya, za, ma, (int)na, nsa, 0, 0, tps, Gs, eps2, part, slab, bslab, npa,
+                                               xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0);
+    NB_HIP(c, hipGetLastError());
+    accel_sym_boundary_f32_kernel<KS, U, TJ, POT><<<nb_launch, BLOCK, 0, c->stream>>>(slab, bslab, nsa, 0, 0, tps, Gs, nsb, npb, 1, b0);
     NB_HIP(c, hipGetLastError());
     // A's sinks of this pass: complete after it
     const int i_begin = b0 * SET, i_end = (int)std::min<int64_t>(na, (int64_t)(b0 + nb_sets) * SET);
-    accel_sym_reduce_f32_kernel<<<(i_end - i_begin + 255) / 256, 256, 0, c->stream>>>(part, groups, nullptr, 0, i_end, npa, G, uniform ? ma : nullptr,
-                                                                                       nullptr, 1, 1, aax, aay, aaz, flags & NB_ACCUMULATE, phi_a, i_begin);
+    accel_sym_reduce_f32_kernel<<<(i_end - i_begin + 255) / 256, 256, 0, c->stream>>>(part, Gs, nb_launch, (long long)tps * HS, SET, b0, nullptr, 0, i_end, npa, G,
+                                                                                       uniform ? ma : nullptr, nullptr, 1, 1, aax, aay, aaz,
+                                                                                       flags & NB_ACCUMULATE, phi_a, i_begin);
     NB_HIP(c, hipGetLastError());
     // B's sums: this pass' slots, added to what earlier passes left
-    accel_sym_reduce_f32_kernel<<<(int)((nb + 255) / 256), 256, 0, c->stream>>>(nullptr, 0, slab, nb_sets, (int)nb, npb, G, uniform ? ma : nullptr,
+    accel_sym_reduce_f32_kernel<<<(int)((nb + 255) / 256), 256, 0, c->stream>>>(nullptr, 0, 0, 0, SET, 0, slab, nb_sets, (int)nb, npb, G, uniform ? ma : nullptr,
                                                                                  nullptr, 1, 1, bax, bay, baz, b0 > 0, phi_b, 0);
     NB_HIP(c, hipGetLastError());
   }
@@ -429,13 +517,13 @@ int run_cross(nb_ctx* c, const float* xa, const float* ya, const float* za, cons
 }
 
 // options of the pair-symmetric kernels: the context's (nb_set_option) or, where unset, the process-wide defaults from the environment
-struct SymOpt { long long mode, min_n, budget, groups, ks; };
+struct SymOpt { long long mode, min_n, budget, blocks, rounds, ks; };
 SymOpt sym_options(const nb_ctx* c) {
   static const long long env_mode = env_ll("NB_F32_SYM", 1), env_min_n = env_ll("NB_F32_SYM_MIN_N", 32768),
-                         env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_groups = env_ll("NB_F32_SYM_GROUPS", 0),
-                         env_ks = env_ll("NB_F32_SYM_KS", 0);
+                         env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_blocks = env_ll("NB_F32_SYM_BLOCKS", 0),
+                         env_rounds = env_ll("NB_F32_SYM_ROUNDS", 1), env_ks = env_ll("NB_F32_SYM_KS", 0);
   return SymOpt{c->sym_enable >= 0 ? c->sym_enable : env_mode, c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
-                c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_groups, env_ks};
+                c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_blocks, env_rounds, env_ks};
 }
 
 }  // namespace
@@ -447,7 +535,7 @@ int nb_launch_accel_sym_f32(nb_ctx* c, const float* x, const float* y, const flo
   *taken = 0;
   c->last_accel_sym = false;
   const SymOpt opt = sym_options(c);
-  const long long mode = opt.mode, min_n = opt.min_n, budget = opt.budget, env_groups = opt.groups, env_ks = opt.ks;
+  const long long mode = opt.mode, min_n = opt.min_n, budget = opt.budget, env_ks = opt.ks;
   if (!mode || n < min_n || n >= (1ll << 31) - 65536 || n <= BLOCK * 4) return NB_OK;
   // Sinks per lane (set = 256 * KS particles). Equal masses, large n: 12 sinks x 1 source per step (244 VGPRs; fewest accumulator round trips
   // per pair: 159.6 ms at N = 2^20 against 163.7 with 8 sinks x 2 sources, one box); per-particle masses carry two more registers per sink
@@ -459,7 +547,7 @@ int nb_launch_accel_sym_f32(nb_ctx* c, const float* x, const float* y, const flo
   if (ks == 12 && items(12, tj) < 3300) ks = 8;
   if (ks == 8 && items(8, tj) < 700) ks = 4;
   if (env_ks == 4 || env_ks == 8 || (env_ks == 12 && (flags & NB_UNIFORM_MASS) && !phi)) ks = (int)env_ks;
-#define NB_RUN(K, UU, PT) run_sym<K, UU, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups, phi)
+#define NB_RUN(K, UU, PT) run_sym<K, UU, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, opt.blocks, opt.rounds, phi)
   const int rc = phi ? (ks == 8 ? NB_RUN(8, 1, true) : NB_RUN(4, 2, true))
                      : (ks == 12 ? NB_RUN(12, 1, false) : ks == 8 ? NB_RUN(8, 2, false) : NB_RUN(4, 2, false));
 #undef NB_RUN
@@ -487,7 +575,7 @@ int nb_launch_accel_cross_f32(nb_ctx* c, const float* xa, const float* ya, const
   int ks = (flags & NB_UNIFORM_MASS) && !pot ? 12 : 8;      // as for a set on itself (nb_launch_accel_sym_f32)
   if (ks == 12 && items(12) < 3300) ks = 8;
   if (ks == 8 && items(8) < 700) ks = 4;
-#define NB_RUN(K, UU, PT) run_cross<K, UU, PT>(c, xa, ya, za, ma, na, xb, yb, zb, mb, nb, eps2, G, aax, aay, aaz, bax, bay, baz, phi_a, phi_b, flags, budget)
+#define NB_RUN(K, UU, PT) run_cross<K, UU, PT>(c, xa, ya, za, ma, na, xb, yb, zb, mb, nb, eps2, G, aax, aay, aaz, bax, bay, baz, phi_a, phi_b, flags, budget, opt.blocks, opt.rounds)
   const int rc = pot ? (ks == 8 ? NB_RUN(8, 1, true) : NB_RUN(4, 2, true))
                      : (ks == 12 ? NB_RUN(12, 1, false) : ks == 8 ? NB_RUN(8, 2, false) : NB_RUN(4, 2, false));
 #undef NB_RUN

@@ -32,57 +32,79 @@ template <bool UNIFORM> __device__ inline d4 ld_src(const d4* p) {
   return *p;
 }
 
+// ---- how the work of a launch is dealt to the blocks: equal shares of STEPS, exactly as in accel_sym_f32.hip (see the comment there) -------
+__host__ __device__ inline long long part_begin(long long k, long long G, int B) { return k >= B ? G : ((k * G / B) & ~1LL); }
+__host__ __device__ inline int part_block_of(long long s, long long G, int B) {       // the block whose range holds step s
+  int k = (int)(s * B / G);
+  if (k > B - 1) k = B - 1;
+  if (k + 1 < B && part_begin(k + 1, G, B) <= s) ++k;
+  return k;
+}
+__device__ inline int sym_set_of(int b, int o, int cross, int nsets, int nsets_src, int H) {
+  if (cross) return (b + o) % nsets_src;
+  const int d = o <= H ? o : nsets / 2; const int c = b + d; return c >= nsets ? c - nsets : c;
+}
+
 template <int KS, int TJ, bool GUARD, bool UNIFORM, bool POT>
 __global__ void __launch_bounds__(BLOCK)
 accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z, const double* __restrict__ m,
-                     int n, int nsets, int H, int o_begin, int o_end, int t_per_group, double eps2,
-                     double* __restrict__ part, double* __restrict__ slab, size_t n_pad,
+                     int n, int nsets, int H, int o_begin, int tps, long long G, double eps2,
+                     double* __restrict__ part, double* __restrict__ slab, double* __restrict__ bslab, size_t n_pad,
                      const double* __restrict__ xs, const double* __restrict__ ys, const double* __restrict__ zs, const double* __restrict__ ms,
                      int n_src, int nsets_src, size_t n_pad_src, int cross, int b0) {
   // cross = 0: the set on itself (xs.. are the same arrays); cross = 1: block A = (x..) against a different block B = (xs..), every A-B pair
-  // two-sided, B's sums to slab slot blockIdx.x (see accel_sym_f32.hip)
+  // two-sided, B's sums to slab slot b - b0 (see accel_sym_f32.hip). The launch's steps g = ((bb * tps + tau) * TJ + t) are dealt to the
+  // blocks in equal shares; a tile cut by a block boundary leaves the second block's share in the bslab.
   static_assert(TJ % BLOCK == 0 && TJ % 2 == 0, "shape");
   constexpr int SET = BLOCK * KS;
   constexpr int AS = TJ + 64;
   constexpr int LPT = TJ / BLOCK;
   constexpr int QT = SET / TJ;
+  constexpr int HS = TJ;             // steps per tile (one source per step)
   static_assert(SET % TJ == 0, "a set is a whole number of tiles");
   constexpr int NC = POT ? 4 : 3;    // POT: the pair potential rides along as a fourth component on both sides
   __shared__ d4 tile[AS];
   __shared__ double acc[WAVES][NC][AS];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int b = b0 + blockIdx.x;
-  const int i0 = b * SET + tid;
   const double far = 1e150;          // UNIFORM padding: y = r2^-1/2 ~ 1e-150, y^3 underflows to exactly 0
+  const int nblk = gridDim.x, kb = blockIdx.x;
+  const long long g_begin = part_begin(kb, G, nblk), g_end = part_begin(kb + 1, G, nblk);
+  const long long S = (long long)tps * HS;
 
   double px[KS], py[KS], pz[KS], pm[KS], fx[KS], fy[KS], fz[KS], fp[KS];
+  auto load_sinks = [&](int b) {
+    const int i0 = b * SET + tid;
 #pragma unroll
-  for (int k = 0; k < KS; ++k) {
-    const int i = i0 + k * BLOCK;
-    const bool ok = i < n;
-    const int ic = ok ? i : n - 1;
-    if (UNIFORM) { px[k] = ok ? x[ic] : far; py[k] = ok ? y[ic] : far; pz[k] = ok ? z[ic] : far; pm[k] = 0.0; }
-    else { px[k] = x[ic]; py[k] = y[ic]; pz[k] = z[ic]; pm[k] = ok ? m[ic] : 0.0; }   // padded sinks: zero mass, they push nothing
-    fx[k] = 0.0; fy[k] = 0.0; fz[k] = 0.0; fp[k] = 0.0;
-  }
+    for (int k = 0; k < KS; ++k) {
+      const int i = i0 + k * BLOCK;
+      const bool ok = i < n;
+      const int ic = ok ? i : n - 1;
+      if (UNIFORM) { px[k] = ok ? x[ic] : far; py[k] = ok ? y[ic] : far; pz[k] = ok ? z[ic] : far; pm[k] = 0.0; }
+      else { px[k] = x[ic]; py[k] = y[ic]; pz[k] = z[ic]; pm[k] = ok ? m[ic] : 0.0; }   // padded sinks: zero mass, they push nothing
+      fx[k] = 0.0; fy[k] = 0.0; fz[k] = 0.0; fp[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(px[k]), "+v"(py[k]), "+v"(pz[k]), "+v"(pm[k]));
+  };
+  auto store_sinks = [&](int b, int seg) {
+    double* pp = part + (size_t)seg * NC * n_pad;
+    const int i0 = b * SET + tid;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int i = i0 + k * BLOCK;
+      if (i < n) { pp[i] = fx[k]; pp[n_pad + i] = fy[k]; pp[2 * n_pad + i] = fz[k]; if (POT) pp[3 * n_pad + i] = fp[k]; }
+    }
+  };
   double e2 = eps2;
   asm volatile("" : "+v"(e2));
 
   for (int e = tid; e < WAVES * NC * AS; e += BLOCK) (&acc[0][0][0])[e] = 0.0;
 
-  // the (offset, tile of the set) pairs of this launch, o_begin * QT .. o_end * QT, are dealt to the groups y in runs of t_per_group
-  const int t_lo = o_begin * QT + blockIdx.y * t_per_group;
-  const int t_hi = min(o_end * QT, t_lo + t_per_group);
-  const int ntiles = max(0, t_hi - t_lo);
-  auto set_of = [&](int o) {
-    if (cross) return (b + o) % nsets_src;
-    const int d = o <= H ? o : nsets / 2; int c = b + d; return c >= nsets ? c - nsets : c;
-  };
-
   d4 stage[LPT];
-  auto fetch = [&](int T) {
-    const int c = set_of((t_lo + T) / QT), q = (t_lo + T) % QT;
+  auto fetch = [&](long long tile_id) {
+    const int bb = (int)(tile_id / tps), tau = (int)(tile_id - (long long)bb * tps);
+    const int c = sym_set_of(b0 + bb, o_begin + tau / QT, cross, nsets, nsets_src, H), q = tau % QT;
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
       const int j = c * SET + q * TJ + l * BLOCK + tid;
@@ -98,15 +120,13 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
     if (tid < 64) tile[TJ + tid] = stage[0];
   };
 
-  if (ntiles > 0) { fetch(0); commit(); }
-#pragma unroll
-  for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(px[k]), "+v"(py[k]), "+v"(pz[k]), "+v"(pm[k]));
+  if (g_begin < g_end) { fetch(g_begin / HS); commit(); }
   __syncthreads();
 
   const d4* tl = tile + lane;
   double* ac = &acc[wv][0][lane];
 
-  auto walk = [&](auto symtag) {
+  auto walk = [&](auto symtag, int t_lo, int t_hi) {
     constexpr bool SYM = decltype(symtag)::value;
     auto step = [&](const d4& s, d4& nx, int t) {
       double gx = 0.0, gy = 0.0, gz = 0.0, gp = 0.0;
@@ -139,19 +159,33 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
         ac[0 * AS + t] = gx; ac[1 * AS + t] = gy; ac[2 * AS + t] = gz; if (POT) ac[3 * AS + t] = gp;
       }
     };
-    d4 sa = ld_src<UNIFORM>(tl), sb;
-    for (int t = 0; t < TJ; t += 2) { step(sa, sb, t); step(sb, sa, t + 1); }
+    d4 sa = ld_src<UNIFORM>(tl + t_lo), sb;
+    for (int t = t_lo; t < t_hi; t += 2) { step(sa, sb, t); step(sb, sa, t + 1); }
   };
 
-  for (int T = 0; T < ntiles; ++T) {
-    const int o = (t_lo + T) / QT, q = (t_lo + T) % QT;
+  int cur = -1, seg = 0;
+  for (long long g = g_begin; g < g_end;) {
+    const long long tile_id = g / HS;
+    const int t_lo = (int)(g - tile_id * HS);
+    const int t_hi = (int)((long long)HS < t_lo + (g_end - g) ? (long long)HS : t_lo + (g_end - g));
+    const int bb = (int)(tile_id / tps), tau = (int)(tile_id - (long long)bb * tps);
+    const int o = o_begin + tau / QT, q = tau % QT;
     const bool sym = cross || (o >= 1 && o <= H);
-    if (T + 1 < ntiles) fetch(T + 1);
-    if (sym) walk(std::true_type{}); else walk(std::false_type{});
+    if (bb != cur) {
+      if (cur >= 0) store_sinks(b0 + cur, seg);
+      seg = cur < 0 ? kb - part_block_of((long long)bb * S, G, nblk) : 0;
+      cur = bb;
+      load_sinks(b0 + bb);
+    }
+    const long long g_next = g + (t_hi - t_lo);
+    if (g_next < g_end) fetch(g_next / HS);
+    if (sym) walk(std::true_type{}, t_lo, t_hi); else walk(std::false_type{}, t_lo, t_hi);
     __syncthreads();
     if (sym) {
-      const int c = set_of(o);
-      double* sl = slab + (size_t)(cross ? (int)blockIdx.x : o - max(o_begin, 1)) * NC * n_pad_src + (size_t)c * SET + (size_t)q * TJ;
+      const int c = sym_set_of(b0 + bb, o, cross, nsets, nsets_src, H);
+      double* sl = t_lo == 0 ? slab + (size_t)(cross ? bb : o - max(o_begin, 1)) * NC * n_pad_src + (size_t)c * SET + (size_t)q * TJ
+                             : bslab + (size_t)kb * NC * TJ;
+      const size_t cstride = t_lo == 0 ? n_pad_src : (size_t)TJ;
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc)
         for (int e = tid; e < TJ; e += BLOCK) {
@@ -162,24 +196,42 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
 #pragma unroll
             for (int w2 = 0; w2 < WAVES; ++w2) { v += acc[w2][cc][TJ + e]; acc[w2][cc][TJ + e] = 0.0; }
           }
-          sl[(size_t)cc * n_pad_src + e] = v;
+          sl[(size_t)cc * cstride + e] = v;
         }
     }
-    if (T + 1 < ntiles) commit();
+    if (g_next < g_end) commit();
     __syncthreads();
+    g = g_next;
   }
-
-  double* pp = part + (size_t)blockIdx.y * NC * n_pad;
-#pragma unroll
-  for (int k = 0; k < KS; ++k) {
-    const int i = i0 + k * BLOCK;
-    if (i < n) { pp[i] = fx[k]; pp[n_pad + i] = fy[k]; pp[2 * n_pad + i] = fz[k]; if (POT) pp[3 * n_pad + i] = fp[k]; }
-  }
+  if (cur >= 0) store_sinks(b0 + cur, seg);
 }
 
-// a[c][i] (+)= g * ( sum_y part[y][c][i] + sum_s slab[s][c][i] ), fixed order; several passes collect in `tot` first
+// slab entry of a tile cut by a block boundary += the share of the block that started inside it
+template <int KS, int TJ, bool POT>
+__global__ void __launch_bounds__(BLOCK)
+accel_sym_boundary_f64_kernel(double* __restrict__ slab, const double* __restrict__ bslab, int nsets, int H, int o_begin, int tps, long long G,
+                              int nsets_src, size_t n_pad_src, int cross, int b0) {
+  constexpr int NC = POT ? 4 : 3, SET = BLOCK * KS, QT = SET / TJ, HS = TJ;
+  const int kb = blockIdx.x, nblk = gridDim.x;
+  const long long g = part_begin(kb, G, nblk);
+  if (g >= part_begin(kb + 1, G, nblk)) return;
+  const long long tile_id = g / HS;
+  if (g == tile_id * HS) return;
+  const int bb = (int)(tile_id / tps), tau = (int)(tile_id - (long long)bb * tps);
+  const int o = o_begin + tau / QT, q = tau % QT;
+  if (!(cross || (o >= 1 && o <= H))) return;
+  const int c = sym_set_of(b0 + bb, o, cross, nsets, nsets_src, H);
+  double* sl = slab + (size_t)(cross ? bb : o - max(o_begin, 1)) * NC * n_pad_src + (size_t)c * SET + (size_t)q * TJ;
+  const double* bs = bslab + (size_t)kb * NC * TJ;
+  for (int cc = 0; cc < NC; ++cc)
+    for (int e = threadIdx.x; e < TJ; e += BLOCK) sl[(size_t)cc * n_pad_src + e] += bs[cc * TJ + e];
+}
+
+// a[c][i] (+)= g * ( sum_seg part[seg][c][i] + sum_s slab[s][c][i] ), fixed order; several passes collect in `tot` first. The part slots of
+// a particle are those of the blocks that shared its sink set (nblk = 0: no part slab) — see accel_sym_f32.hip
 __global__ void __launch_bounds__(256)
-accel_sym_reduce_f64_kernel(const double* __restrict__ part, int ngroups, const double* __restrict__ slab, int nslots, int n, size_t n_pad,
+accel_sym_reduce_f64_kernel(const double* __restrict__ part, long long Gs, int nblk, long long S, int set_size, int b0,
+                            const double* __restrict__ slab, int nslots, int n, size_t n_pad,
                             double G, const double* __restrict__ m0, double* __restrict__ tot, int first, int last,
                             double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az, int accumulate, double* __restrict__ phi,
                             int i_begin) {
@@ -187,10 +239,14 @@ accel_sym_reduce_f64_kernel(const double* __restrict__ part, int ngroups, const 
   const int i = i_begin + blockIdx.x * blockDim.x + threadIdx.x;      // particles [i_begin, n)
   if (i >= n) return;
   double sx = 0.0, sy = 0.0, sz = 0.0, sp = 0.0;
-  for (int g = 0; g < ngroups; ++g) {
-    const double* p = part + (size_t)g * nc * n_pad;
-    sx += p[i]; sy += p[n_pad + i]; sz += p[2 * n_pad + i];
-    if (phi) sp += p[3 * n_pad + i];
+  if (nblk > 0) {
+    const long long bb = i / set_size - b0;
+    const int nseg = part_block_of((bb + 1) * S - 1, Gs, nblk) - part_block_of(bb * S, Gs, nblk) + 1;
+    for (int g = 0; g < nseg; ++g) {
+      const double* p = part + (size_t)g * nc * n_pad;
+      sx += p[i]; sy += p[n_pad + i]; sz += p[2 * n_pad + i];
+      if (phi) sp += p[3 * n_pad + i];
+    }
   }
 #pragma unroll 8
   for (int s = 0; s < nslots; ++s) {
@@ -214,10 +270,29 @@ long long env_ll(const char* name, long long dflt) {
   return v && *v ? atoll(v) : dflt;
 }
 
+// blocks of a launch: the device's resident block slots for this kernel x rounds, at most one per tile (accel_sym_f32.hip: sym_blocks)
+template <typename K>
+int sym_blocks(nb_ctx* c, K kernel, long long tiles, long long env_blocks, long long env_rounds) {
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
+  long long nblk = env_blocks > 0 ? env_blocks : (long long)per_cu * cus * std::max<long long>(1, env_rounds);
+  if (nblk > tiles) nblk = tiles;
+  if (nblk > 65535 * 16) nblk = 65535 * 16;
+  return (int)std::max<long long>(1, nblk);
+}
+
+template <int KS, int TJ, bool POT>
+auto sym_kernel(bool guard, bool uniform) {
+  if (guard) return uniform ? accel_sym_f64_kernel<KS, TJ, true, true, POT> : accel_sym_f64_kernel<KS, TJ, true, false, POT>;
+  return uniform ? accel_sym_f64_kernel<KS, TJ, false, true, POT> : accel_sym_f64_kernel<KS, TJ, false, false, POT>;
+}
+
 template <int KS, bool POT>
 int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const double* m, int64_t n,
-            double eps2, double G, double* ax, double* ay, double* az, int flags, long long budget, long long env_groups, double* phi) {
+            double eps2, double G, double* ax, double* ay, double* az, int flags, long long budget, long long env_blocks, long long env_rounds, double* phi) {
   constexpr int TJ = 256, SET = BLOCK * KS, NC = POT ? 4 : 3;
+  constexpr int QT = SET / TJ, HS = TJ;
   const int nsets = (int)((n + SET - 1) / SET);
   const size_t n_pad = (size_t)nsets * SET;
   const int H = (nsets - 1) / 2;
@@ -225,47 +300,45 @@ int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const 
   const size_t slot_bytes = NC * n_pad * sizeof(double);
   // clamped in 64 bits BEFORE the cast: a budget meant as "unlimited" (INT64_MAX) must not wrap
   int slots_per_pass = (int)std::min<long long>(std::max<long long>(1, budget / (long long)slot_bytes), (long long)std::max(H, 1));
-  // pass 0 takes o = 0 and the first two-sided offsets, the last pass also the one-sided half offset
-  constexpr int QT = SET / TJ;                               // tiles per set
-  // groups: ~4096 blocks PER PASS (see accel_f32.hip's split sweep; a pass of a large problem must not shrink to a round or two of blocks)
-  int groups_target = env_groups > 0 ? (int)env_groups : (4096 + nsets - 1) / nsets;
-  if (groups_target < 1) groups_target = 1;
-  const int max_groups_pass = groups_target + 1;
-  const size_t part_bytes = (size_t)max_groups_pass * NC * n_pad * sizeof(double);
-  int npass;
-  size_t slab_bytes, tot_bytes;
+  const bool uniform = (flags & NB_UNIFORM_MASS) != 0;
+  const bool guard = !(eps2 > 0.0);
+  const int accumulate = flags & NB_ACCUMULATE;
+  const auto kernel = sym_kernel<KS, TJ, POT>(guard, uniform);
+  int npass, nblk_max, nseg_max;
+  size_t part_bytes, bslab_bytes, slab_bytes, tot_bytes;
   for (;;) {                                                 // the allocator may refuse the scratch: fewer slots per pass, then give up (one-sided kernel)
     npass = H > 0 ? (H + slots_per_pass - 1) / slots_per_pass : 1;
+    nblk_max = sym_blocks(c, kernel, (long long)nsets * std::min(n_o, slots_per_pass + 2) * QT, env_blocks, env_rounds);
+    nseg_max = nblk_max / nsets + 2;
+    part_bytes = (size_t)nseg_max * NC * n_pad * sizeof(double);
+    bslab_bytes = (size_t)nblk_max * NC * TJ * sizeof(double);
     slab_bytes = (size_t)slots_per_pass * slot_bytes;
     tot_bytes = npass > 1 ? NC * (size_t)n * sizeof(double) : 0;
-    const int rc = nb_try_ensure_work(c, part_bytes + slab_bytes + tot_bytes, c->sym_scratch_limit);
+    const int rc = nb_try_ensure_work(c, part_bytes + bslab_bytes + slab_bytes + tot_bytes, c->sym_scratch_limit);
     if (rc == NB_OK) break;
     if (rc != NB_WORK_UNAVAILABLE || slots_per_pass <= 1) return rc;
     slots_per_pass = (slots_per_pass + 1) / 2;
   }
-  double* part = reinterpret_cast<double*>(c->work);
-  double* slab = reinterpret_cast<double*>(reinterpret_cast<char*>(c->work) + part_bytes);
-  double* tot = npass > 1 ? reinterpret_cast<double*>(reinterpret_cast<char*>(c->work) + part_bytes + slab_bytes) : nullptr;
-  const bool uniform = (flags & NB_UNIFORM_MASS) != 0;
-  const bool guard = !(eps2 > 0.0);
-  const int accumulate = flags & NB_ACCUMULATE;
+  char* w = reinterpret_cast<char*>(c->work);
+  double* part = reinterpret_cast<double*>(w);
+  double* bslab = reinterpret_cast<double*>(w + part_bytes);
+  double* slab = reinterpret_cast<double*>(w + part_bytes + bslab_bytes);
+  double* tot = npass > 1 ? reinterpret_cast<double*>(w + part_bytes + bslab_bytes + slab_bytes) : nullptr;
   for (int ps = 0; ps < npass; ++ps) {
     const int s_begin = 1 + ps * slots_per_pass, s_end = 1 + std::min(H, (ps + 1) * slots_per_pass);
     const int o_begin = ps == 0 ? 0 : s_begin;
     const int o_end = (ps == npass - 1) ? n_o : s_end;
-    const int pass_tiles = (o_end - o_begin) * QT;             // (offset, tile) pairs of this pass, dealt to the groups in runs of tpg
-    const int tpg = std::max(1, (pass_tiles + groups_target - 1) / groups_target);
-    const int ngroups = (pass_tiles + tpg - 1) / tpg;
+    const int tps = (o_end - o_begin) * QT;                   // tiles per sink set in this pass
+    const long long Gs = (long long)nsets * tps * HS;        // steps of this pass
+    const int nblk = std::min(nblk_max, sym_blocks(c, kernel, (long long)nsets * tps, env_blocks, env_rounds));
     const int nslots = std::max(0, s_end - s_begin);
-    if (ngroups > max_groups_pass) return nb_fail(c, NB_ERR_ARG, "accel_sym_f64: internal group count");
-    dim3 grid(nsets, ngroups);
-#define NB_SYM_GO(GD, UF) accel_sym_f64_kernel<KS, TJ, GD, UF, POT><<<grid, BLOCK, 0, c->stream>>>( \
-    x, y, z, m, (int)n, nsets, H, o_begin, o_end, tpg, eps2, part, slab, n_pad, x, y, z, m, (int)n, nsets, n_pad, 0, 0)
-    if (guard) { if (uniform) NB_SYM_GO(true, true); else NB_SYM_GO(true, false); }
-    else       { if (uniform) NB_SYM_GO(false, true); else NB_SYM_GO(false, false); }
-#undef NB_SYM_GO
+    if (nblk / nsets + 2 > nseg_max) return nb_fail(c, NB_ERR_ARG, "accel_sym_f64: internal slot count");
+    kernel<<<nblk, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, nsets, H, o_begin, tps, Gs, eps2, part, slab, bslab, n_pad,
+                                          x, y, z, m, (int)n, nsets, n_pad, 0, 0);
     NB_HIP(c, hipGetLastError());
-    accel_sym_reduce_f64_kernel<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(part, ngroups, slab, nslots, (int)n, n_pad, G,
+    accel_sym_boundary_f64_kernel<KS, TJ, POT><<<nblk, BLOCK, 0, c->stream>>>(slab, bslab, nsets, H, o_begin, tps, Gs, nsets, n_pad, 0, 0);
+    NB_HIP(c, hipGetLastError());
+    accel_sym_reduce_f64_kernel<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(part, Gs, nblk, (long long)tps * HS, SET, 0, slab, nslots, (int)n, n_pad, G,
                                                                                  uniform ? m : nullptr, tot, ps == 0, ps == npass - 1,
                                                                                  ax, ay, az, accumulate, phi, 0);
     NB_HIP(c, hipGetLastError());
@@ -278,45 +351,51 @@ template <int KS, bool POT>
 int run_cross(nb_ctx* c, const double* xa, const double* ya, const double* za, const double* ma, int64_t na,
               const double* xb, const double* yb, const double* zb, const double* mb, int64_t nb,
               double eps2, double G, double* aax, double* aay, double* aaz, double* bax, double* bay, double* baz,
-              double* phi_a, double* phi_b, int flags, long long budget) {
+              double* phi_a, double* phi_b, int flags, long long budget, long long env_blocks, long long env_rounds) {
   constexpr int TJ = 256, SET = BLOCK * KS, NC = POT ? 4 : 3;
+  constexpr int QT = SET / TJ, HS = TJ;
   const int nsa = (int)((na + SET - 1) / SET), nsb = (int)((nb + SET - 1) / SET);
   const size_t npa = (size_t)nsa * SET, npb = (size_t)nsb * SET;
   const size_t slot_bytes = NC * npb * sizeof(double);
   int sets_per_pass = (int)std::min<long long>(std::max<long long>(1, budget / (long long)slot_bytes), (long long)std::max(nsa, 1));
-  constexpr int QT = SET / TJ;
-  int groups, tpg;
-  size_t part_bytes;
+  const bool uniform = (flags & NB_UNIFORM_MASS) != 0;
+  const bool guard = !(eps2 > 0.0);
+  const auto kernel = sym_kernel<KS, TJ, POT>(guard, uniform);
+  const int tps = nsb * QT;                                   // every set of B, tile by tile
+  int nblk_max, nseg_max;
+  size_t part_bytes, bslab_bytes;
   for (;;) {                                                 // as run_sym: fewer sets of A per pass if the allocator refuses, then give up
-    groups = (4096 + sets_per_pass - 1) / sets_per_pass;                    // ~4096 blocks per launch
-    if (groups > nsb * QT) groups = nsb * QT;
-    if (groups < 1) groups = 1;
-    tpg = (nsb * QT + groups - 1) / groups;                                 // (set of B, tile) pairs per group
-    groups = (nsb * QT + tpg - 1) / tpg;
-    part_bytes = (size_t)groups * NC * npa * sizeof(double);
-    const int rc = nb_try_ensure_work(c, part_bytes + (size_t)sets_per_pass * slot_bytes, c->sym_scratch_limit);
+    nblk_max = sym_blocks(c, kernel, (long long)sets_per_pass * tps, env_blocks, env_rounds);
+    nseg_max = nblk_max / sets_per_pass + 2;                 // blocks that can share one sink set (+ the two cut ends)
+    const int rest = nsa % sets_per_pass;                    // a last pass with fewer sets shares its blocks among fewer sets
+    if (rest > 0) nseg_max = std::max(nseg_max, sym_blocks(c, kernel, (long long)rest * tps, env_blocks, env_rounds) / rest + 2);
+    part_bytes = (size_t)nseg_max * NC * npa * sizeof(double);
+    bslab_bytes = (size_t)nblk_max * NC * TJ * sizeof(double);
+    const int rc = nb_try_ensure_work(c, part_bytes + bslab_bytes + (size_t)sets_per_pass * slot_bytes, c->sym_scratch_limit);
     if (rc == NB_OK) break;
     if (rc != NB_WORK_UNAVAILABLE || sets_per_pass <= 1) return rc;
     sets_per_pass = (sets_per_pass + 1) / 2;
   }
-  double* part = reinterpret_cast<double*>(c->work);
-  double* slab = reinterpret_cast<double*>(reinterpret_cast<char*>(c->work) + part_bytes);
-  const bool uniform = (flags & NB_UNIFORM_MASS) != 0;
-  const bool guard = !(eps2 > 0.0);
+  char* w = reinterpret_cast<char*>(c->work);
+  double* part = reinterpret_cast<double*>(w);
+  double* bslab = reinterpret_cast<double*>(w + part_bytes);
+  double* slab = reinterpret_cast<double*>(w + part_bytes + bslab_bytes);
   for (int b0 = 0; b0 < nsa; b0 += sets_per_pass) {
     const int nb_sets = std::min(sets_per_pass, nsa - b0);
-    dim3 grid(nb_sets, groups);
-#define NB_SYM_GO(GD, UF) accel_sym_f64_kernel<KS, TJ, GD, UF, POT><<<grid, BLOCK, 0, c->stream>>>( \
-    xa, ya, za, ma, (int)na, nsa, 0, 0, nsb, tpg, eps2, part, slab, npa, xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0)
-    if (guard) { if (uniform) NB_SYM_GO(true, true); else NB_SYM_GO(true, false); }
-    else       { if (uniform) NB_SYM_GO(false, true); else NB_SYM_GO(false, false); }
-#undef NB_SYM_GO
+    const long long Gs = (long long)nb_sets * tps * HS;
+    const int nb_launch = std::min(nblk_max, sym_blocks(c, kernel, (long long)nb_sets * tps, env_blocks, env_rounds));
+    if (nb_launch / nb_sets + 2 > nseg_max) return nb_fail(c, NB_ERR_ARG, "accel_sym_f64: internal slot count");
+    kernel<<<nb_launch, BLOCK, 0, c->stream>>>(xa, ya, za, ma, (int)na, nsa, 0, 0, tps, Gs, eps2, part, slab, bslab, npa,
+                                               xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0);
+    NB_HIP(c, hipGetLastError());
+    accel_sym_boundary_f64_kernel<KS, TJ, POT><<<nb_launch, BLOCK, 0, c->stream>>>(slab, bslab, nsa, 0, 0, tps, Gs, nsb, npb, 1, b0);
     NB_HIP(c, hipGetLastError());
     const int i_begin = b0 * SET, i_end = (int)std::min<int64_t>(na, (int64_t)(b0 + nb_sets) * SET);
-    accel_sym_reduce_f64_kernel<<<(i_end - i_begin + 255) / 256, 256, 0, c->stream>>>(part, groups, nullptr, 0, i_end, npa, G, uniform ? ma : nullptr,
-                                                                                       nullptr, 1, 1, aax, aay, aaz, flags & NB_ACCUMULATE, phi_a, i_begin);
+    accel_sym_reduce_f64_kernel<<<(i_end - i_begin + 255) / 256, 256, 0, c->stream>>>(part, Gs, nb_launch, (long long)tps * HS, SET, b0, nullptr, 0, i_end, npa, G,
+                                                                                       uniform ? ma : nullptr, nullptr, 1, 1, aax, aay, aaz,
+                                                                                       flags & NB_ACCUMULATE, phi_a, i_begin);
     NB_HIP(c, hipGetLastError());
-    accel_sym_reduce_f64_kernel<<<(int)((nb + 255) / 256), 256, 0, c->stream>>>(nullptr, 0, slab, nb_sets, (int)nb, npb, G, uniform ? ma : nullptr,
+    accel_sym_reduce_f64_kernel<<<(int)((nb + 255) / 256), 256, 0, c->stream>>>(nullptr, 0, 0, 0, SET, 0, slab, nb_sets, (int)nb, npb, G, uniform ? ma : nullptr,
                                                                                  nullptr, 1, 1, bax, bay, baz, b0 > 0, phi_b, 0);
     NB_HIP(c, hipGetLastError());
   }
@@ -324,13 +403,13 @@ int run_cross(nb_ctx* c, const double* xa, const double* ya, const double* za, c
 }
 
 // options of the pair-symmetric kernels: the context's (nb_set_option) or, where unset, the process-wide defaults from the environment
-struct SymOpt { long long mode, min_n, budget, groups, ks; };
+struct SymOpt { long long mode, min_n, budget, blocks, rounds, ks; };
 SymOpt sym_options(const nb_ctx* c) {
   static const long long env_mode = env_ll("NB_F64_SYM", 1), env_min_n = env_ll("NB_F64_SYM_MIN_N", 16384),
-                         env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_groups = env_ll("NB_F64_SYM_GROUPS", 0),
-                         env_ks = env_ll("NB_F64_SYM_KS", 0);
+                         env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_blocks = env_ll("NB_F64_SYM_BLOCKS", 0),
+                         env_rounds = env_ll("NB_F64_SYM_ROUNDS", 1), env_ks = env_ll("NB_F64_SYM_KS", 0);
   return SymOpt{c->sym_enable >= 0 ? c->sym_enable : env_mode, c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
-                c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_groups, env_ks};
+                c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_blocks, env_rounds, env_ks};
 }
 
 }  // namespace
@@ -341,7 +420,7 @@ int nb_launch_accel_sym_f64(nb_ctx* c, const double* x, const double* y, const d
   *taken = 0;
   c->last_accel_sym = false;
   const SymOpt opt = sym_options(c);
-  const long long mode = opt.mode, min_n = opt.min_n, budget = opt.budget, env_groups = opt.groups, env_ks = opt.ks;
+  const long long mode = opt.mode, min_n = opt.min_n, budget = opt.budget, env_ks = opt.ks;
   if (!mode || n < min_n || n >= (1ll << 31) - 65536 || n <= BLOCK * 2) return NB_OK;
   // sinks per lane: 8 for large n (N = 2^19, equal masses: 80.4 ms against 85.1 with 4 and 96.9 with 2; the one-sided kernel: 126.9), smaller
   // sets for smaller n so that the launch still has ~1000 (set, offset, tile) work items (sweep: profiles/r03_sym_kernel_development_log.txt)
@@ -350,7 +429,7 @@ int nb_launch_accel_sym_f64(nb_ctx* c, const double* x, const double* y, const d
   if (items(8) < 1000) ks = 4;
   if (ks == 4 && items(4) < 1000) ks = 2;
   if (env_ks == 2 || env_ks == 4 || env_ks == 8) ks = (int)env_ks;
-#define NB_RUN(K, PT) run_sym<K, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, env_groups, phi)
+#define NB_RUN(K, PT) run_sym<K, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, opt.blocks, opt.rounds, phi)
   const int rc = phi ? (ks == 8 ? NB_RUN(8, true) : ks == 4 ? NB_RUN(4, true) : NB_RUN(2, true))
                      : (ks == 8 ? NB_RUN(8, false) : ks == 4 ? NB_RUN(4, false) : NB_RUN(2, false));
 #undef NB_RUN
@@ -376,7 +455,7 @@ int nb_launch_accel_cross_f64(nb_ctx* c, const double* xa, const double* ya, con
   int ks = 8;
   if (items(8) < 1000) ks = 4;
   if (ks == 4 && items(4) < 1000) ks = 2;
-#define NB_RUN(K, PT) run_cross<K, PT>(c, xa, ya, za, ma, na, xb, yb, zb, mb, nb, eps2, G, aax, aay, aaz, bax, bay, baz, phi_a, phi_b, flags, budget)
+#define NB_RUN(K, PT) run_cross<K, PT>(c, xa, ya, za, ma, na, xb, yb, zb, mb, nb, eps2, G, aax, aay, aaz, bax, bay, baz, phi_a, phi_b, flags, budget, opt.blocks, opt.rounds)
   const int rc = pot ? (ks == 8 ? NB_RUN(8, true) : ks == 4 ? NB_RUN(4, true) : NB_RUN(2, true))
                      : (ks == 8 ? NB_RUN(8, false) : ks == 4 ? NB_RUN(4, false) : NB_RUN(2, false));
 #undef NB_RUN

@@ -144,6 +144,72 @@ def mesh_options(p: Dict[str, Any], gravity, n: int) -> Dict[str, Any]:
     return out
 
 
+def _pick(d, component: str = "matter", default=None):
+    """A per-component option dict of CONCEPT ({'default': v} / {'matter': v} / {'all': v} / a bare value)."""
+    if not isinstance(d, dict):
+        return default if d is None else d
+    for key in (component, "all", "default"):
+        if key in d:
+            return d[key]
+    return default
+
+
+def powerspec_options(p: Dict[str, Any], n: int, boxsize: float) -> Dict[str, Any]:
+    """`powerspec_options` of the reference's parameter files (TheFeedingPipeline/NN.param:28-45; SnapVsPK/Uncertain.param:29-60, whose
+    comments cite CONCEPT's documentation for the defaults), reduced to what the estimator here acts on:
+
+      'upstream gridsize' {'particles': 'cbrt(Ñ)'}      -> gridsize of the CIC mesh (an expression in N / Ñ, or a number)
+      'interpolation' {'default': 'CIC'}                -> only 'CIC' is implemented (the thesis changed CONCEPT's 'PCS' to 'CIC')
+      'deconvolve', 'interlace', 'realization correction' -> booleans
+      'k_max' {'default': 'nyquist'}                    -> 'nyquist' (= pi gridsize / boxsize), a number, or an expression in nyquist / k_min / k_max
+      'bins per decade' {'default': {'  4*k_min': 4, '100*k_min': 40}} -> [(k, bins per decade)] sorted by k; keys are expressions in
+                          k_min = 2 pi / boxsize, k_max, nyquist and gridsize; None when the key is absent (the CLI then keeps its
+                          linear bins of width 2 k_min)
+      'tophat' {'default': 8*Mpc/h}                     -> radius of the sigma printed in the table header
+      'significant figures' {'default': 8}              -> digits of the table
+
+    Values are validated here so that a parameter file the estimator cannot honour fails before the run."""
+    po = p.get("powerspec_options", {})
+    if not isinstance(po, dict):
+        raise ParamError("powerspec_options must be a dict")
+    cb = round(n ** (1.0 / 3.0)) if n > 0 else 0
+    up = po.get("upstream gridsize", {})
+    up = up.get("particles", up.get("default", None)) if isinstance(up, dict) else up
+    grid = _gridsize_value(up, n) if up is not None and n > 0 else cb
+    interp = str(_pick(po.get("interpolation"), default="CIC")).upper()
+    if interp != "CIC":
+        raise ParamError(f"powerspec_options['interpolation'] = {interp!r}: only 'CIC' is implemented")
+    k_min = 2.0 * math.pi / float(boxsize)
+    nyq = math.pi * grid / float(boxsize) if grid else math.inf
+    env = {"k_min": k_min, "nyquist": nyq, "gridsize": grid, "sqrt": math.sqrt, "pi": math.pi, "π": math.pi, "inf": math.inf}
+
+    def number(v, what, extra=None):
+        if isinstance(v, (int, float)):
+            return float(v)
+        try:
+            return float(eval(str(v).strip(), {"__builtins__": {}}, dict(env, **(extra or {}))))
+        except Exception as e:
+            raise ParamError(f"powerspec_options[{what!r}]: cannot evaluate {v!r}: {e}") from e
+    k_max = number(_pick(po.get("k_max"), default="nyquist"), "k_max")
+    bpd = _pick(po.get("bins per decade"), default=None)
+    table = None
+    if bpd is not None:
+        if isinstance(bpd, (int, float)):
+            table = [(k_min, float(bpd))]
+        elif isinstance(bpd, dict) and bpd:
+            table = sorted((number(k, "bins per decade", {"k_max": k_max}), float(v)) for k, v in bpd.items())
+        else:
+            raise ParamError("powerspec_options['bins per decade'] must be a number or a non-empty {k: bins} dict")
+        if any(not (k > 0 and b > 0) for k, b in table):
+            raise ParamError("powerspec_options['bins per decade']: wavenumbers and bin densities must be positive")
+    return {"gridsize": int(grid), "interpolation": interp,
+            "deconvolve": bool(_pick(po.get("deconvolve"), default=True)), "interlace": bool(_pick(po.get("interlace"), default=True)),
+            "realization_correction": bool(_pick(po.get("realization correction"), default=True)),
+            "k_max": k_max, "bins_per_decade": table,
+            "tophat": number(_pick(po.get("tophat"), default=8.0 / (p["h"] if "h" in p else 0.6736)), "tophat") if po.get("tophat") is not None or True else None,
+            "significant_figures": int(_pick(po.get("significant figures"), default=8))}
+
+
 def settings(p: Dict[str, Any]) -> Dict[str, Any]:
     """The keys the engine acts on, validated (SURVEY.md §8f-4 list)."""
     ic = p.get("initial_conditions")
@@ -173,7 +239,7 @@ def settings(p: Dict[str, Any]) -> Dict[str, Any]:
         "snapshot_dir": out_dirs.get("snapshot"), "powerspec_dir": out_dirs.get("powerspec"),
         "snapshot_times": [float(t) for t in snap_times],
         "powerspec_times": [float(t) for t in (times.get("powerspec", []) if isinstance(times, dict) else [])],
-        "gravity": gravity, "mesh": mesh,
+        "gravity": gravity, "mesh": mesh, "powerspec": powerspec_options(p, n, float(p["boxsize"])),
         "lpt": int(p.get("realization_options", {}).get("LPT", 1)) if isinstance(p.get("realization_options", {}), dict) else 1,
         "random_seeds": dict(p.get("random_seeds", {})),
         "primordial_spectrum": dict(p.get("primordial_spectrum", {})),

@@ -108,3 +108,11 @@ def rel_err(a, ref):
     """per-particle |a - ref| / |ref|"""
     a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
     return np.linalg.norm(a - ref, axis=1) / np.linalg.norm(ref, axis=1)
+
+
+def note(label, value, tol=None):
+    """Measured-error log for calibrating tolerances (NB_TEST_ERRLOG=<file>): label, measured value, tolerance in force."""
+    path = os.environ.get("NB_TEST_ERRLOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{label}\t{value:.3e}\t{'' if tol is None else format(tol, '.1e')}\n")

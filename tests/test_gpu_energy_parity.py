@@ -7,17 +7,20 @@
 including eps = 0 with exactly coincident particles (the GUARD instantiations, which drop a pair with a zero denominator — the rule the
 oracle's force and potential sums share). Below those sizes tests/test_gpu_parity.py and test_gpu_fused_potential.py cover the small-n paths.
 
-Tolerances (relative error of the total potential energy U / of a per-sink potential phi_i against the fp64 oracle on the same rounded inputs):
-fp64 1e-12; fp32 1e-6 for U (measured <= 2e-7: fp32 pair terms, partial sums flushed to fp64 per tile) and 2e-6 for a single phi_i."""
+Tolerances (relative error of the total potential energy U / of a per-sink potential phi_i against the fp64 oracle on the same rounded
+inputs), within 5-7x of the measured errors (profiles/r04_parity_measured_errors.txt): U fp32 5e-8 (measured <= 8.3e-9: fp32 pair terms, partial
+sums flushed to fp64 per tile, and the errors of 10^9 terms average out), fp64 5e-15 (measured <= 7.8e-16); phi_i fp32 5e-7 (measured <= 1.05e-7),
+fp64 2e-13 (measured <= 3.6e-14)."""
 import numpy as np
 import pytest
 
 import bachelor_thesis_n_body_amd as nb
+from conftest import note
 
 pytestmark = pytest.mark.gpu
 DTYPES = [np.float32, np.float64]
-UTOL = {np.float32: 1e-6, np.float64: 1e-12}
-PTOL = {np.float32: 2e-6, np.float64: 1e-12}
+UTOL = {np.float32: 5e-8, np.float64: 5e-15}
+PTOL = {np.float32: 5e-7, np.float64: 2e-13}
 
 
 def _cloud(n, dtype, general, seed=31):
@@ -57,6 +60,7 @@ def test_nb_energy_matches_oracle_at_large_n(dtype, n, general, coracle):
         k, u = e.energy(0.01, 1.7)
     assert k == pytest.approx(coracle.kinetic(v, m), rel=1e-6 if dtype == np.float32 else 1e-13)
     ref = coracle.potential(p, m, 0.01, 1.7)
+    note(f"nb_energy U n={n} {np.dtype(dtype).name} {'general' if general else 'uniform'}", abs(u / ref - 1), UTOL[dtype])
     assert abs(u / ref - 1) < UTOL[dtype], f"U {u!r} oracle {ref!r} rel {abs(u / ref - 1):.3e}"
 
 
@@ -74,6 +78,7 @@ def test_nb_step_energy_matches_oracle_at_large_n(dtype, n, general, coracle):
     p, v, m = _f64(st)
     assert K[0] == pytest.approx(coracle.kinetic(v, m), rel=1e-6 if dtype == np.float32 else 1e-13)
     ref = coracle.potential(p, m, 0.01)
+    note(f"nb_step_energy U n={n} {np.dtype(dtype).name} {'general' if general else 'uniform'}", abs(U[0] / ref - 1), UTOL[dtype])
     assert abs(U[0] / ref - 1) < UTOL[dtype], f"U {U[0]!r} oracle {ref!r} rel {abs(U[0] / ref - 1):.3e}"
 
 
@@ -95,13 +100,15 @@ def test_zero_softening_with_coincident_particles_at_large_n(dtype, general, n, 
         sym = e.last_accel_symmetric()
     assert sym == (n >= (32768 if dtype == np.float32 else 16384))
     assert np.isfinite(u) and np.isfinite(U[0]) and np.isfinite(a).all()
-    # close pairs dominate the eps = 0 sum: one fp32 term carries 6e-8 relative error whatever the accumulation does
-    tol = 3e-6 if dtype == np.float32 else 1e-12
+    tol = UTOL[dtype]
+    note(f"eps=0 nb_energy U n={n} {np.dtype(dtype).name} {'general' if general else 'uniform'}", abs(u / ref - 1), tol)
+    note(f"eps=0 nb_step_energy U n={n} {np.dtype(dtype).name} {'general' if general else 'uniform'}", abs(U[0] / ref - 1), tol)
     assert abs(u / ref - 1) < tol, f"nb_energy: rel {abs(u / ref - 1):.3e}"
     assert abs(U[0] / ref - 1) < tol, f"nb_step_energy: rel {abs(U[0] / ref - 1):.3e}"
-    # the coincident particles feel identical forces
-    np.testing.assert_array_equal(a[17], a[3])
-    np.testing.assert_array_equal(a[900], a[901])
+    # the coincident particles feel the same force (to rounding: they sit in different lanes / sets, i.e. other summation orders)
+    ftol = 1e-6 if dtype == np.float32 else 1e-13
+    af = a.astype(np.float64)
+    assert np.linalg.norm(af[17] - af[3]) < ftol * np.linalg.norm(af[3]) and np.linalg.norm(af[900] - af[901]) < ftol * np.linalg.norm(af[901])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -138,5 +145,6 @@ def test_two_block_fused_potential_matches_oracle(dtype, general, na, nb_, eps, 
     ga, gb = phi_a.cpu().numpy()[ia], phi_b.cpu().numpy()[ib]
     assert np.isfinite(ga).all() and np.isfinite(gb).all()
     tol = PTOL[dtype]
+    note(f"two-block phi na={na} nb={nb_} eps={eps} {np.dtype(dtype).name} {'general' if general else 'uniform'}", max(np.abs(ga / ra - 1).max(), np.abs(gb / rb - 1).max()), tol)
     assert np.abs(ga / ra - 1).max() < tol and np.abs(gb / rb - 1).max() < tol, (np.abs(ga / ra - 1).max(), np.abs(gb / rb - 1).max())
     k.close()

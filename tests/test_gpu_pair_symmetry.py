@@ -4,16 +4,16 @@ law, bit-reproducibility, independence of the number of slab passes. All calls g
 
 Tolerances (per-particle |da| / |a| against the fp64 oracle on the same rounded inputs): fp64 <= 2e-13; fp32 <= 1e-6 from n = 32768 on
 (measured 8e-8 .. 2e-7, profiles/r03_sym_kernel_development_log.txt: fp32 pair terms, partial sums flushed to fp64 per tile / set) and
-<= 3e-6 below (measured up to 1.3e-6 at n = 4096 .. 16384, where a few central particles have |a| far below the typical pair term) —
-within 5x of what is measured, so a lost flush or a mis-added slab fails."""
+<= 1e-5 below (measured up to 2.3e-6 at n = 1500 .. 16384 — profiles/r04_parity_measured_errors.txt — where a few central particles have
+|a| far below the typical pair term); fp64 measured <= 4.2e-14. All within 5x of what is measured, so a lost flush or a mis-added slab fails."""
 import numpy as np
 import pytest
 
 import bachelor_thesis_n_body_amd as nb
-from conftest import rel_err
+from conftest import rel_err, note
 
 pytestmark = pytest.mark.gpu
-TOL = {np.float32: 3e-6, np.float64: 2e-13}
+TOL = {np.float32: 1e-5, np.float64: 2e-13}
 
 
 def tol(dtype, n):
@@ -56,6 +56,7 @@ def test_symmetric_kernel_matches_oracle(dtype, general, n, coracle):
     idx = np.arange(n) if n <= 20000 else _sample(n)
     ref = coracle.accel(s.pos.astype(np.float64), s.mass.astype(np.float64), 0.01, sinks=s.pos[idx].astype(np.float64))
     err = rel_err(a[idx], ref)
+    note(f"sym accel vs oracle n={n} {np.dtype(dtype).name} {'general' if general else 'uniform'}", err.max(), tol(dtype, n))
     assert np.isfinite(a).all() and err.max() < tol(dtype, n), f"max {err.max():.3e} median {np.median(err):.3e}"
 
 
@@ -77,7 +78,9 @@ def test_symmetric_and_one_sided_kernels_agree_to_rounding(dtype, general, n):
         assert e.last_accel_symmetric()
     # both sum the same pair terms, in different orders, with fp32 partials flushed to fp64 (fp32) / plain fp64
     d = rel_err(a_sym, a_one.astype(np.float64))
-    assert d.max() < ((3e-6 if n < 32768 else 1e-6) if dtype == np.float32 else 2e-13), f"{d.max():.3e}"
+    note(f"sym vs one-sided n={n} {np.dtype(dtype).name} {'general' if general else 'uniform'}", d.max())
+    # (two fp32 results against each other: twice the rounding of one against the oracle — measured up to 1.1e-6 at n = 50 000)
+    assert d.max() < ((4e-6 if n < 32768 else 2e-6) if dtype == np.float32 else 2e-13), f"{d.max():.3e}"
     assert np.array_equal(a_sym, a_again), "the pair-symmetric kernel is not bit-reproducible"
 
 
@@ -106,7 +109,8 @@ def test_result_does_not_depend_on_the_number_of_slab_passes(dtype, general):
         a2 = e.accel(0.01)
         assert e.last_accel_symmetric()
     d = rel_err(a2, a1.astype(np.float64))
-    assert d.max() < (2e-7 if dtype == np.float32 else 1e-14), f"{d.max():.3e}"
+    # (fp32: the passes cut the work into other block shares — a tile walked by two blocks adds two fp32 partial sums instead of one)
+    assert d.max() < (6e-7 if dtype == np.float32 else 1e-14), f"{d.max():.3e}"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -122,38 +126,43 @@ def test_scratch_budget_extremes_and_allocator_refusal(dtype):
         e.set_option("sym_slab_bytes", (1 << 63) - 1)
         a1 = e.accel(0.01)
         assert e.last_accel_symmetric() and np.array_equal(a1, a0)
-        e.set_option("sym_slab_bytes", -1)
-        e.set_option("sym_scratch_limit", 24 << 20)          # the one-pass request is ~60 MB (fp32) / ~110 MB (fp64) here
-        assert e.get_option("sym_scratch_limit") == 24 << 20
-        a2 = e.accel(0.01)
-        assert e.last_accel_symmetric()
-        e.set_option("sym_scratch_limit", 1 << 20)           # not even the sink-sum slab fits: one-sided kernel
-        a3 = e.accel(0.01)
-        assert not e.last_accel_symmetric()
-        e.set_option("sym_scratch_limit", -1)
-        a4 = e.accel(0.01)
-        assert e.last_accel_symmetric() and np.array_equal(a4, a0)
-    t = 1e-6 if dtype == np.float32 else 2e-13
-    assert rel_err(a2, a0.astype(np.float64)).max() < (2e-7 if dtype == np.float32 else 1e-14)
-    assert rel_err(a3, a0.astype(np.float64)).max() < t
+    # The limit is on what is ASKED of the allocator (scratch a context already holds is used): fresh contexts, the limit halved from
+    # 1 GiB down to 256 KiB. Generous limits leave the launch as it is; below the one-pass request it takes more passes; below what even one
+    # slab slot needs the one-sided kernel runs — and at no limit does the evaluation fail or change beyond the summation order.
+    flags, results = [], []
+    for shift in range(30, 17, -1):
+        with _engine(n, dtype, s) as e:
+            e.set_option("sym_scratch_limit", 1 << shift)
+            assert e.get_option("sym_scratch_limit") == 1 << shift
+            results.append(e.accel(0.01))
+            flags.append(e.last_accel_symmetric())
+            if shift == 18:
+                e.set_option("sym_scratch_limit", -1)
+                a4 = e.accel(0.01)
+                assert e.last_accel_symmetric() and np.array_equal(a4, a0)
+    assert flags[0] and not flags[-1] and flags == sorted(flags, reverse=True), flags        # symmetric ... symmetric, one-sided ... one-sided
+    assert np.array_equal(results[0], a0)
+    t = 2e-6 if dtype == np.float32 else 2e-13               # two fp32 kernels against each other: twice the rounding of one
+    for f, r in zip(flags, results):
+        assert rel_err(r, a0.astype(np.float64)).max() < ((6e-7 if dtype == np.float32 else 1e-13) if f else t)
     # the two-block entry under the same limits
     import torch
     tdt = torch.float32 if dtype == np.float32 else torch.float64
-    k = nb.HipKernels(0)
     na = 30000
     blk = lambda lo, hi: torch.from_numpy(np.vstack([s.pos[lo:hi].T, s.mass[None, lo:hi]])).contiguous().cuda()
     A, B = blk(0, na), blk(na, n)
     res = []
-    for limit, sym in ((-1, True), (12 << 20, True), (1 << 18, False)):
+    for limit, sym in ((-1, True), (1 << 18, False)):
+        k = nb.HipKernels(0)
         k.set_option("sym_scratch_limit", limit)
         acc_a, acc_b = torch.zeros((3, na), dtype=tdt, device="cuda"), torch.zeros((3, n - na), dtype=tdt, device="cuda")
         k.accel_pair(A, na, B, n - na, 0.01, 1.0, acc_a, acc_b, False, uniform_mass=True)
         assert k.last_accel_symmetric() == sym, limit
         torch.cuda.synchronize()
         res.append((acc_a.cpu().numpy().T.astype(np.float64), acc_b.cpu().numpy().T.astype(np.float64)))
+        k.close()
     for ra, rb in res[1:]:
         assert rel_err(ra, res[0][0]).max() < t and rel_err(rb, res[0][1]).max() < t
-    k.close()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -123,3 +123,59 @@ def test_pk_table_is_rescaled_by_A_s(tmp_path):
     a.pk_table_As = 4.21e-9
     np.testing.assert_allclose(concept._load_pk_table(a, s)[:, 1], 0.5 * 1e3 / k)          # the file's A_s is 2.105e-9
     assert concept._load_pk_table(a, s).shape == (5, 2)
+
+
+def test_powerspec_options_of_the_reference_parameter_files():
+    """`powerspec_options` (TheFeedingPipeline/NN.param:28-45, SnapVsPK/Uncertain.param:29-60 incl. 'bins per decade' :50-55)."""
+    if not REF.exists():
+        pytest.skip("reference tree not present")
+    s = params.settings(params.parse(REF / "TheFeedingPipeline" / "NN.param"))["powerspec"]
+    assert s["gridsize"] == 32 and s["interpolation"] == "CIC" and s["deconvolve"] and s["interlace"] and s["realization_correction"]
+    assert s["k_max"] == pytest.approx(np.pi * 32 / 500.0) and s["bins_per_decade"] is None and s["significant_figures"] == 8
+    p = params.parse(REF / "SnapVsPK" / "Uncertain.param", overrides={"_tag": "job"})     # Ucertain.py:22-67 prepends the job's tag
+    s = params.settings(p)["powerspec"]
+    k_min = 2 * np.pi / 1000.0
+    assert s["gridsize"] == 64 and s["k_max"] == pytest.approx(np.pi * 64 / 1000.0)
+    assert s["bins_per_decade"] == [(pytest.approx(4 * k_min), 4.0), (pytest.approx(100 * k_min), 40.0)]
+    h = p["H0"] / (100 * params.UNITS["km"] / params.UNITS["s"])
+    assert s["tophat"] == pytest.approx(8.0 / h, rel=1e-12)
+
+
+def test_powerspec_options_validation(tmp_path):
+    f = _write(tmp_path)
+    base = f.read_text(encoding="utf-8")
+    def with_options(text):
+        g = tmp_path / "po.param"
+        g.write_text(base + "\npowerspec_options = " + text + "\n", encoding="utf-8")
+        return params.settings(params.parse(g))["powerspec"]
+    s = with_options("{'upstream gridsize': {'particles': '2*cbrt(Ñ)'}, 'k_max': {'default': '0.5*nyquist'}, 'bins per decade': {'default': 10},"
+                     " 'deconvolve': {'default': False}, 'realization correction': {'matter': False}, 'significant figures': {'default': 5}}")
+    assert s["gridsize"] == 16 and s["k_max"] == pytest.approx(0.5 * np.pi * 16 / 500.0) and s["bins_per_decade"] == [(pytest.approx(2 * np.pi / 500), 10.0)]
+    assert s["deconvolve"] is False and s["realization_correction"] is False and s["significant_figures"] == 5
+    with pytest.raises(params.ParamError, match="only 'CIC'"):
+        with_options("{'interpolation': {'default': 'PCS'}}")
+    with pytest.raises(params.ParamError, match="cannot evaluate"):
+        with_options("{'k_max': {'default': 'nyquist*foo'}}")
+    with pytest.raises(params.ParamError, match="positive"):
+        with_options("{'bins per decade': {'default': {'k_min': -3}}}")
+
+
+def test_bins_per_decade_rule_against_the_reference_table():
+    """The documented default {'4*k_min': 4, '100*k_min': 40} on a 64^3 / 500 Mpc box: CONCEPT's table lists 16 bins with
+    3, 25, 124, 418, ... independent modes (PPPMP3M/PP/powerspec/powerspec_a=1.00:11-26) — the rule reproduces the bin count, the first
+    three counts exactly and the others to 10 % (CONCEPT's own routine is not in the repository)."""
+    from bachelor_thesis_n_body_amd import cosmo
+    ref = np.array([3, 25, 124, 418, 730, 1012, 1408, 1841, 2770, 3520, 4642, 6019, 7958, 9892, 12661, 15506])
+    L, n = 500.0, 64
+    kf = 2 * np.pi / L
+    e = cosmo.bins_per_decade_edges([(4 * kf, 4.0), (100 * kf, 40.0)], kf, np.pi * n / L)
+    assert len(e) == 17 and e[0] == pytest.approx(kf * 10 ** (-1 / 8)) and e[-1] == pytest.approx(np.pi * n / L) and np.all(np.diff(e) > 0)
+    f = np.fft.fftfreq(n, 1.0 / n)
+    kk = kf * np.sqrt(f[:, None, None] ** 2 + f[None, :, None] ** 2 + f[None, None, :] ** 2).ravel()
+    e[-1] *= 1 + 1e-12
+    cnt = np.histogram(kk[kk > 0], bins=e)[0] // 2
+    assert list(cnt[:3]) == [3, 25, 124] and np.abs(cnt / ref - 1).max() < 0.10 and abs(cnt.sum() - ref.sum()) <= 1
+    # a constant density is plain logarithmic binning; the remainder narrower than half a bin joins the last bin
+    e = cosmo.bins_per_decade_edges([(1.0, 5.0)], 1.0, 100.0)
+    np.testing.assert_allclose(e[1:-1] / e[:-2], 10 ** 0.2, rtol=1e-12)
+    assert e[-1] == 100.0 and e[-1] / e[-2] >= 10 ** 0.1
