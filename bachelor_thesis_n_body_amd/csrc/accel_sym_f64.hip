@@ -276,7 +276,12 @@ int sym_blocks(nb_ctx* c, K kernel, long long tiles, long long env_blocks, long 
   int per_cu = 0, cus = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
-  long long nblk = env_blocks > 0 ? env_blocks : (long long)per_cu * cus * std::max<long long>(1, env_rounds);
+  const long long slots = (long long)per_cu * cus;
+  // rounds: 1 would be the static optimum if every slot ran at the same speed; measured (profiles/r04_sym_block_shares_ab.txt, N = 2^20, one
+  // box) 163.4 ms with 1 round, 160.0 / 158.8 / 157.6 with 2 / 4 / 8: the slots do NOT run equally fast, and shares an eighth the size let
+  // the dispatcher even that out. Small launches keep >= 4 tiles per block (at N = 65 536 the round count makes no measurable difference).
+  const long long rounds = env_rounds > 0 ? env_rounds : std::min<long long>(8, std::max<long long>(1, tiles / (4 * slots)));
+  long long nblk = env_blocks > 0 ? env_blocks : slots * rounds;
   if (nblk > tiles) nblk = tiles;
   if (nblk > 65535 * 16) nblk = 65535 * 16;
   return (int)std::max<long long>(1, nblk);
@@ -407,7 +412,7 @@ struct SymOpt { long long mode, min_n, budget, blocks, rounds, ks; };
 SymOpt sym_options(const nb_ctx* c) {
   static const long long env_mode = env_ll("NB_F64_SYM", 1), env_min_n = env_ll("NB_F64_SYM_MIN_N", 16384),
                          env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_blocks = env_ll("NB_F64_SYM_BLOCKS", 0),
-                         env_rounds = env_ll("NB_F64_SYM_ROUNDS", 1), env_ks = env_ll("NB_F64_SYM_KS", 0);
+                         env_rounds = env_ll("NB_F64_SYM_ROUNDS", 0), env_ks = env_ll("NB_F64_SYM_KS", 0);
   return SymOpt{c->sym_enable >= 0 ? c->sym_enable : env_mode, c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
                 c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_blocks, env_rounds, env_ks};
 }
