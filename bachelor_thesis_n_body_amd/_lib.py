@@ -47,6 +47,7 @@ SIGNATURES = {
     "nb_clock_probe_begin": (_int, [_int, _dbl, C.POINTER(_vp)]),
     "nb_clock_probe_stop": (_int, [_vp, _vp]),
     "nb_clock_probe_end": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_dbl)]),
+    "nb_clock_probe_end_xcd": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_dbl), _int]),
     "nb_set_state": (_int, [_vp] + [_vp] * 7),
     "nb_get_state": (_int, [_vp] + [_vp] * 7),
     "nb_accel": (_int, [_vp, _dbl, _dbl, _vp, _vp, _vp]),

@@ -277,6 +277,18 @@ class ClockProbe:
         _lib.check(None, self._lib.nb_clock_probe_end(h, C.byref(mhz), C.byref(win)), "nb_clock_probe_end")
         return mhz.value, win.value
 
+    def end_xcd(self) -> Tuple[float, float, list]:
+        """(mean MHz, window ms, [MHz of XCD 0, 1, ...]): the probe runs one wave per XCD (nb_clock_probe_end_xcd)."""
+        if not self._h:
+            raise RuntimeError("ClockProbe.end() called twice")
+        mhz, win = C.c_double(), C.c_double()
+        per = (C.c_double * 8)()
+        h, self._h = self._h, C.c_void_p()
+        n = self._lib.nb_clock_probe_end_xcd(h, C.byref(mhz), C.byref(win), per, 8)
+        if n < 0:
+            _lib.check(None, n, "nb_clock_probe_end_xcd")
+        return mhz.value, win.value, [float(per[i]) for i in range(n)]
+
     def __del__(self):
         if getattr(self, "_h", None):
             try:

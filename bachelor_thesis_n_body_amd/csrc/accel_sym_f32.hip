@@ -28,8 +28,10 @@
 //  * accuracy as accel_f32: fp32 partial sums live for one tile (sinks) / one set of 256*KS sinks (sources) and are then widened.
 #include "nb_common.h"
 #include "../../include/nbody_amd.h"
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -71,12 +73,13 @@ __device__ inline int sym_set_of(int b, int o, int cross, int nsets, int nsets_s
 }
 
 template <int KS, int U, int TJ, bool GUARD, bool UNIFORM, bool POT>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, 2)      // two blocks per CU (two waves per SIMD): at most 256 registers, AGPRs included
 accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ m,
                      int n, int nsets, int H, int o_begin, int tps, long long G, float eps2,
                      double* __restrict__ part, float* __restrict__ slab, float* __restrict__ bslab, size_t n_pad,
                      const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs, const float* __restrict__ ms,
-                     int n_src, int nsets_src, size_t n_pad_src, int cross, int b0) {
+                     int n_src, int nsets_src, size_t n_pad_src, int cross, int b0, long long* __restrict__ trace) {
+  // trace (debugging aid, normally null; NB_SYM_TRACE=<file>): [block][start tick, end tick, HW_ID | XCC_ID << 32] of the constant-rate counter
   // cross = 0: the set (x, y, z, m) on itself (xs.. are the same arrays). cross = 1: block A = (x..) against a DIFFERENT block B = (xs..):
   // sink set b of A walks every set of B two-sidedly (o = 0 .. nsets_src - 1 -> set (b + o) mod nsets_src); B's sums go to slab slot
   // b - b0 (one slot per sink set of this launch).
@@ -98,6 +101,13 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
   const int nblk = gridDim.x, kb = blockIdx.x;
   const long long g_begin = part_begin(kb, G, nblk), g_end = part_begin(kb + 1, G, nblk);
   const long long S = (long long)tps * HS;                 // steps per sink set
+  if (trace && tid == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    trace[3 * kb] = __builtin_amdgcn_s_memrealtime();
+    trace[3 * kb + 2] = (long long)hw | ((long long)xcc << 32);
+  }
 
   v2f px[KP], py[KP], pz[KP], pm[KP];
   double tx[KS], ty[KS], tz[KS], tp[KS];
@@ -159,6 +169,10 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
 
   const float4* tl = tile + lane;
   float* ac = &acc[wv][0][lane * AW];
+  // Two blocks share a CU (one wave of each per SIMD) and the issue arbiter prefers the OLDER wave: of two co-resident blocks with equal
+  // work the first-dispatched finishes far ahead (325 against 774 us at N = 65 536) and the other then runs alone at ~70 % of the issue rate
+  // two waves reach — the tail of a one-round launch. Letting the waves take turns at s_setprio (by their own step count, or by time slices
+  // of the constant-rate counter) was built and measured: no gain (profiles/r04_priority_turns_between_coresident_waves_negative_result.txt).
 
   auto walk = [&](auto symtag, int t_lo, int t_hi) {
     constexpr bool SYM = decltype(symtag)::value;
@@ -304,6 +318,7 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
     g = g_next;
   }
   if (cur >= 0) store_sinks(b0 + cur, seg);
+  if (trace && tid == 0) trace[3 * kb + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // slab entry of a tile cut by a block boundary += the share of the block that started inside it (one such block per tile: B <= G / HS)
@@ -449,9 +464,23 @@ int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const flo
     const int nblk = std::min(nblk_max, sym_blocks(c, kernel, (long long)nsets * tps, env_blocks, env_rounds));
     const int nslots = std::max(0, s_end - s_begin);
     if (nblk / nsets + 2 > nseg_max) return nb_fail(c, NB_ERR_ARG, "accel_sym_f32: internal slot count");
+    static const char* trace_path = getenv("NB_SYM_TRACE");      // debugging aid: per-block start / end ticks and placement of every launch
+    long long* trace = nullptr;
+    if (trace_path && *trace_path) NB_HIP(c, hipMalloc(&trace, (size_t)nblk * 3 * sizeof(long long)));
     kernel<<<nblk, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, nsets, H, o_begin, tps, Gs, eps2, part, slab, bslab, n_pad,
-                                          x, y, z, m, (int)n, nsets, n_pad, 0, 0);
+                                          x, y, z, m, (int)n, nsets, n_pad, 0, 0, trace);
     NB_HIP(c, hipGetLastError());
+    if (trace) {
+      std::vector<long long> h((size_t)nblk * 3);
+      NB_HIP(c, hipStreamSynchronize(c->stream));
+      NB_HIP(c, hipMemcpy(h.data(), trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      (void)hipFree(trace);
+      if (FILE* f = fopen(trace_path, "a")) {
+        fprintf(f, "# launch n=%lld KS=%d blocks=%d steps=%lld\n", (long long)n, KS, nblk, Gs);
+        for (int k = 0; k < nblk; ++k) fprintf(f, "%d %lld %lld %lld %lld\n", k, h[3 * k], h[3 * k + 1], h[3 * k + 2] & 0xffffffffll, h[3 * k + 2] >> 32);
+        fclose(f);
+      }
+    }
     accel_sym_boundary_f32_kernel<KS, U, TJ, POT><<<nblk, BLOCK, 0, c->stream>>>(slab, bslab, nsets, H, o_begin, tps, Gs, nsets, n_pad, 0, 0);
     NB_HIP(c, hipGetLastError());
     accel_sym_reduce_f32_kernel<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(part, Gs, nblk, (long long)tps * HS, SET, 0, slab, nslots, (int)n, n_pad, G,
@@ -503,7 +532,7 @@ int run_cross(nb_ctx* c, const float* xa, const float* ya, const float* za, cons
     const int nb_launch = std::min(nblk_max, sym_blocks(c, kernel, (long long)nb_sets * tps, env_blocks, env_rounds));
     if (nb_launch / nb_sets + 2 > nseg_max) return nb_fail(c, NB_ERR_ARG, "accel_sym_f32: internal slot count");
     kernel<<<nb_launch, BLOCK, 0, c->stream>>>(xa, ya, za, ma, (int)na, nsa, 0, 0, tps, Gs, eps2, part, slab, bslab, npa,
-                                               xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0);
+                                               xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0, nullptr);
     NB_HIP(c, hipGetLastError());
     accel_sym_boundary_f32_kernel<KS, U, TJ, POT><<<nb_launch, BLOCK, 0, c->stream>>>(slab, bslab, nsa, 0, 0, tps, Gs, nsb, npb, 1, b0);
     NB_HIP(c, hipGetLastError());

@@ -46,7 +46,7 @@ __device__ inline int sym_set_of(int b, int o, int cross, int nsets, int nsets_s
 }
 
 template <int KS, int TJ, bool GUARD, bool UNIFORM, bool POT>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, 2)      // two blocks per CU (two waves per SIMD): at most 256 registers, AGPRs included
 accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z, const double* __restrict__ m,
                      int n, int nsets, int H, int o_begin, int tps, long long G, double eps2,
                      double* __restrict__ part, double* __restrict__ slab, double* __restrict__ bslab, size_t n_pad,

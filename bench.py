@@ -579,7 +579,7 @@ def main():
         timer.enabled = False
         if probe is not None:
             probe.enabled = False
-        clock_mhz, clock_ms = clock.end() if clock is not None else (None, None)
+        clock_mhz, clock_ms, clock_xcd = clock.end_xcd() if clock is not None else (None, None, None)
         clock_min = clock_mhz
         if world > 1:
             t = torch.tensor([elapsed, -(clock_mhz or 0.0)], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
@@ -591,7 +591,7 @@ def main():
         reg = {"name": name, "pairwise": bool(eng.pairwise), "elapsed": elapsed, "symmetric": bool(symmetric),
                "sym_all": bool(symmetric and (world == 1 or eng.pairwise)),      # N ranks: the pair-symmetric schedule makes every hop two-sided
                "k_ms": k_ms, "k_inter": k_inter, "k_count": k_count, "ring": probe.summary() if probe is not None else None,
-               "clock_mhz": clock_mhz, "clock_ms": clock_ms, "clock_min": clock_min}
+               "clock_mhz": clock_mhz, "clock_ms": clock_ms, "clock_min": clock_min, "clock_xcd": clock_xcd}
         hb(f"{name}: region complete")
         return reg
 
@@ -673,7 +673,8 @@ def main():
                                                             if ("pair-symmetric" if pw else "one-sided") not in regs]}
         if clock_mhz:
             simds = 256 * 4
-            r["sustained_clock_mhz"] = clock_mhz
+            r["sustained_clock_mhz"] = clock_mhz            # mean over the XCDs (one probe wave each)
+            r["sustained_clock_mhz_per_xcd"] = best["clock_xcd"]
             r["clock_window_ms"] = clock_ms
             if world > 1:
                 r["sustained_clock_mhz_min_over_ranks"] = clock_min

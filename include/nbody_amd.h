@@ -169,6 +169,9 @@ int nb_clock_probe_begin(int device, double window_ms, nb_clock_probe** probe);
  * before this call has finished, or after window_ms, whichever comes first */
 int nb_clock_probe_stop(nb_clock_probe* probe, void* stream);
 int nb_clock_probe_end(nb_clock_probe* probe, double* mhz, double* window_ms);
+/* the same, and the clock of every XCD separately: the probe runs one wave per XCD (each reports the XCC it ran on); `mhz` is their mean,
+ * xcd_mhz[i] the clock of XCD i (0 where no wave landed). Returns the number of entries written (<= cap), < 0 on error. */
+int nb_clock_probe_end_xcd(nb_clock_probe* probe, double* mhz, double* window_ms, double* xcd_mhz, int cap);
 
 /* ---- host-pointer surface: the drop-in compute_forces()/step()/energy() (SURVEY §8a ⊕1-⊕3) ----
  * "Host-pointer" = the caller hands over HOST buffers, which are copied to the device; the arithmetic always runs on the GPU. The

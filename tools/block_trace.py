@@ -1,0 +1,59 @@
+"""Per-block timeline of the pair-symmetric fp32 kernel (NB_SYM_TRACE): start / end tick of every block on the constant-rate counter and the
+XCD / SE / CU it ran on. Answers: are the resident slots equally fast, are the blocks evenly placed?   python tools/block_trace.py n [n ...]"""
+import os, sys, collections
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+path = "/tmp/nb_sym_trace.txt"
+os.environ["NB_SYM_TRACE"] = path
+import bachelor_thesis_n_body_amd as nb
+
+for n in [int(v) for v in sys.argv[1:]] or [65536]:
+    if os.path.exists(path):
+        os.remove(path)
+    with nb.Engine(n, np.float32) as e:
+        e.set_state(nb.plummer_sphere(n, 0, np.float32))
+        e.accel(0.01, fetch=False)
+        e.accel(0.01, fetch=False)
+    launches, cur = [], None
+    for line in open(path):
+        if line.startswith("#"):
+            cur = []; launches.append((line.strip(), cur))
+        else:
+            cur.append([int(v) for v in line.split()])
+    head, rows = launches[-1]
+    a = np.array(rows, dtype=np.int64)
+    t0 = a[:, 1].min()
+    start, end = (a[:, 1] - t0) / 100.0, (a[:, 2] - t0) / 100.0          # 100 MHz counter -> microseconds
+    hw, xcc = a[:, 3], a[:, 4]
+    cu, sh, se = (hw >> 8) & 0xf, (hw >> 12) & 0x1, (hw >> 13) & 0x7
+    dur = end - start
+    print(head)
+    print(f"  makespan {end.max():.1f} us; block duration mean {dur.mean():.1f} min {dur.min():.1f} max {dur.max():.1f} us; start spread {start.max():.1f} us; "
+          f"sum of durations / (makespan x blocks) = {dur.sum() / (end.max() * len(dur)):.3f}")
+    per_xcc = collections.defaultdict(list)
+    for i in range(len(dur)):
+        per_xcc[int(xcc[i])].append(i)
+    for x in sorted(per_xcc):
+        idx = per_xcc[x]
+        cus = collections.Counter((int(se[i]), int(sh[i]), int(cu[i])) for i in idx)
+        print(f"  XCD {x}: {len(idx)} blocks on {len(cus)} CUs (blocks per CU: {sorted(collections.Counter(cus.values()).items())}); duration mean {dur[idx].mean():.1f} max {dur[idx].max():.1f}; last end {end[idx].max():.1f}")
+    # blocks alone on their CU against blocks that shared it
+    place = collections.Counter((int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i])) for i in range(len(dur)))
+    alone = np.array([place[(int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]))] == 1 for i in range(len(dur))])
+    if alone.any() and (~alone).any():
+        print(f"  blocks alone on a CU: {alone.sum()} (mean {dur[alone].mean():.1f} us); sharing a CU: {(~alone).sum()} (mean {dur[~alone].mean():.1f} us)")
+    # the two blocks of a CU: wave slot of each (HW_ID[3:0] of the block's first wave) and their durations
+    by_cu = collections.defaultdict(list)
+    for i in range(len(dur)):
+        by_cu[(int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]))].append((float(start[i]), float(dur[i]), int(hw[i] & 0xf), int((hw[i] >> 4) & 0x3)))
+    pairs = [sorted(v) for v in by_cu.values() if len(v) == 2 and abs(v[0][0] - v[1][0]) < 50.0]
+    if pairs:
+        d0, d1 = np.array([p[0][1] for p in pairs]), np.array([p[1][1] for p in pairs])
+        print(f"  CUs whose two blocks started together: {len(pairs)}; shorter of the two mean {np.minimum(d0, d1).mean():.1f} us, longer mean {np.maximum(d0, d1).mean():.1f} us; "
+              f"wave slots (first, second block): {sorted(collections.Counter((p[0][2], p[1][2]) for p in pairs).items())}; SIMD of wave 0: {sorted(collections.Counter((p[0][3], p[1][3]) for p in pairs).items())}")
+        print("  first five pairs (start, duration, slot, simd):", pairs[:5])
+    late = start > 0.2 * end.max()
+    print(f"  blocks that started after 20 % of the makespan: {late.sum()}")
+    order = np.argsort(end)
+    print("  ten last blocks to finish (block, start, end, xcd, se, sh, cu):", [(int(a[i, 0]), round(float(start[i]), 1), round(float(end[i]), 1), int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i])) for i in order[-10:]])
