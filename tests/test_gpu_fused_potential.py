@@ -78,7 +78,10 @@ def test_accel_pot_dev_zero_softening_drops_coincident_pairs(dtype):
 @pytest.mark.parametrize("uniform", [False, True])
 @pytest.mark.parametrize("n,eps", [(2, 0.5), (1000, 0.01), (5000, 0.02), (20000, 0.01), (1000, 0.0)])
 def test_step_energy_equals_step_then_energy(dtype, uniform, n, eps):
-    """Trajectory: identical to nb_step's. Energies: the separate O(N^2) potential / kinetic kernels at every step."""
+    """Trajectory: nb_step's — bit for bit where both run the one-sided kernels (same partial-sum structure with and without the potential);
+    from n = 16 384 on an fp64 context takes the pair-symmetric kernels, whose potential-carrying variant has another register footprint,
+    hence another number of resident blocks and other block shares (accel_sym_f32.hip): the same pair terms in another summation order,
+    equal to a few ulp. Energies: the separate O(N^2) potential / kinetic kernels at every step."""
     s = nb.plummer_sphere(n, 23, dtype)
     if not uniform:
         s.mass[:] = (s.mass * np.random.default_rng(1).uniform(0.5, 1.5, n)).astype(dtype)
@@ -95,8 +98,12 @@ def test_step_energy_equals_step_then_energy(dtype, uniform, n, eps):
             k, u = e.energy(eps)
             ks.append(k); us.append(u)
         ref = e.get_state()
-    np.testing.assert_array_equal(fused.pos, ref.pos)
-    np.testing.assert_array_equal(fused.vel, ref.vel)
+    if dtype == np.float64 and n >= 16384:
+        np.testing.assert_allclose(fused.pos, ref.pos, rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(fused.vel, ref.vel, rtol=1e-13, atol=1e-15)
+    else:
+        np.testing.assert_array_equal(fused.pos, ref.pos)
+        np.testing.assert_array_equal(fused.vel, ref.vel)
     np.testing.assert_allclose(K, ks, rtol=1e-13)
     np.testing.assert_allclose(U, us, rtol=3e-6 if dtype == np.float32 else 1e-12)
 

@@ -63,5 +63,6 @@ for P in (1, 2, 4, 8):
     ps = probe.summary() or {}
     print(json.dumps({"virtual_ranks": P, "schedule": "pair-symmetric" if (pairwise and P > 1) else "one-sided", "rank0_kernel_ms": tm.total_ms() / reps, "n": n, "dtype": np.dtype(dtype).name, "sinks_of_rank0": eng.n_loc, "ms_per_force_evaluation": dt * 1e3,
                       "interactions_per_s_of_this_rank": eng.n_loc * float(n) / dt, "projected_whole_job_interactions_per_s": P * eng.n_loc * float(n) / dt,
-                      "hop_comm_ms": ps.get("comm_ms"), "hop_kernel_ms": ps.get("kernel_ms"), "hop_exposed_ms": ps.get("exposed_ms")}), flush=True)
+                      "hop_comm_ms": ps.get("comm_ms"), "hop_kernel_ms": ps.get("kernel_ms"), "hop_exposed_ms": ps.get("exposed_ms"),
+                      "back_comm_ms": ps.get("back_comm_ms"), "back_exposed_ms": ps.get("back_exposed_ms"), "add_ms": ps.get("add_ms")}), flush=True)
 dist.destroy_process_group()
