@@ -391,10 +391,18 @@ long long env_ll(const char* name, long long dflt) {
 // (a tile may be cut once only); NB_F32_SYM_BLOCKS overrides the product.
 template <typename K>
 int sym_blocks(nb_ctx* c, K kernel, long long tiles, long long env_blocks, long long env_rounds) {
-  int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
-  const long long slots = (long long)per_cu * cus;
+  // resident block slots of this kernel on this device: asked of the runtime once per (kernel, device), not on every launch
+  struct Slot { const void* k; int dev; long long slots; };
+  static thread_local std::vector<Slot> cache;
+  long long slots = 0;
+  for (const Slot& e : cache) if (e.k == (const void*)kernel && e.dev == c->device) { slots = e.slots; break; }
+  if (!slots) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
+    slots = (long long)per_cu * cus;
+    cache.push_back(Slot{(const void*)kernel, c->device, slots});
+  }
   // rounds: 1 would be the static optimum if every slot ran at the same speed; measured (profiles/r04_sym_block_shares_ab.txt, N = 2^20, one
   // box) 163.4 ms with 1 round, 160.0 / 158.8 / 157.6 with 2 / 4 / 8: the slots do NOT run equally fast, and shares an eighth the size let
   // the dispatcher even that out. Small launches keep >= 4 tiles per block (at N = 65 536 the round count makes no measurable difference).
@@ -553,7 +561,7 @@ int run_cross(nb_ctx* c, const float* xa, const float* ya, const float* za, cons
 // options of the pair-symmetric kernels: the context's (nb_set_option) or, where unset, the process-wide defaults from the environment
 struct SymOpt { long long mode, min_n, budget, blocks, rounds, ks; };
 SymOpt sym_options(const nb_ctx* c) {
-  static const long long env_mode = env_ll("NB_F32_SYM", 1), env_min_n = env_ll("NB_F32_SYM_MIN_N", 32768),
+  static const long long env_mode = env_ll("NB_F32_SYM", 1), env_min_n = env_ll("NB_F32_SYM_MIN_N", 24576),
                          env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_blocks = env_ll("NB_F32_SYM_BLOCKS", 0),
                          env_rounds = env_ll("NB_F32_SYM_ROUNDS", 0), env_ks = env_ll("NB_F32_SYM_KS", 0);
   return SymOpt{c->sym_enable >= 0 ? c->sym_enable : env_mode, c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -273,10 +274,18 @@ long long env_ll(const char* name, long long dflt) {
 // blocks of a launch: the device's resident block slots for this kernel x rounds, at most one per tile (accel_sym_f32.hip: sym_blocks)
 template <typename K>
 int sym_blocks(nb_ctx* c, K kernel, long long tiles, long long env_blocks, long long env_rounds) {
-  int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
-  const long long slots = (long long)per_cu * cus;
+  // resident block slots of this kernel on this device: asked of the runtime once per (kernel, device), not on every launch
+  struct Slot { const void* k; int dev; long long slots; };
+  static thread_local std::vector<Slot> cache;
+  long long slots = 0;
+  for (const Slot& e : cache) if (e.k == (const void*)kernel && e.dev == c->device) { slots = e.slots; break; }
+  if (!slots) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
+    slots = (long long)per_cu * cus;
+    cache.push_back(Slot{(const void*)kernel, c->device, slots});
+  }
   // rounds: 1 would be the static optimum if every slot ran at the same speed; measured (profiles/r04_sym_block_shares_ab.txt, N = 2^20, one
   // box) 163.4 ms with 1 round, 160.0 / 158.8 / 157.6 with 2 / 4 / 8: the slots do NOT run equally fast, and shares an eighth the size let
   // the dispatcher even that out. Small launches keep >= 4 tiles per block (at N = 65 536 the round count makes no measurable difference).
