@@ -39,13 +39,11 @@ constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// one staged source; equal masses: the 12 bytes of the position only (ds_read_b96 — a b128 read would also write the register of the
-// unused mass, which the compiler re-uses, and stall on that write)
-struct alignas(16) f3 { float x, y, z; };
-template <bool UNIFORM> __device__ inline float4 ld_src(const float4* p) {
-  if (UNIFORM) { const f3 v = *reinterpret_cast<const f3*>(p); return make_float4(v.x, v.y, v.z, 0.f); }
-  return *p;
-}
+// one staged source (16 bytes, one ds_read_b128 per lane). Equal masses: (x, y, z, z) — the packed subtractions take (x, x) and (y, y) from the
+// low / high half of the first register pair by operand selection, and (z, z) IS the second pair (a 12-byte read leaves z alone in an
+// odd-partnered register and costs a v_mov per source to pair it up: 2 of 198 instructions per two steps — measured neutral, A/B on one box:
+// 156.9 / 156.9 against 156.5 / 157.2 ms at N = 2^20; kept because it is the simpler code)
+template <bool UNIFORM> __device__ inline float4 ld_src(const float4* p) { return *p; }
 
 // ---- the work of a launch and how it is dealt to the blocks -------------------------------------------------------------------------
 // Offsets of a launch are numbered o = 0 .. : o = 0 -> d = 0 (one-sided), o = 1 .. H -> d = o (two-sided), o = H + 1 -> d = nsets / 2
@@ -154,8 +152,9 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
       const int j = c * SET + q * TJ + l * BLOCK + tid;
       const bool ok = j < n_src;
       const int jc = ok ? j : n_src - 1;
-      stage[l] = UNIFORM ? make_float4(ok ? xs[jc] : far, ok ? ys[jc] : far, ok ? zs[jc] : far, 0.0f)
-                         : make_float4(xs[jc], ys[jc], zs[jc], ok ? ms[jc] : 0.0f);
+      const float zv = UNIFORM ? (ok ? zs[jc] : far) : zs[jc];
+      stage[l] = UNIFORM ? make_float4(ok ? xs[jc] : far, ok ? ys[jc] : far, zv, zv)
+                         : make_float4(xs[jc], ys[jc], zv, ok ? ms[jc] : 0.0f);
     }
   };
   auto commit = [&]() {
@@ -208,7 +207,7 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
         for (int p = 0; p < KP; ++p) {
           dx[u][p] = v2f{s[u].x, s[u].x} - px[p];
           dy[u][p] = v2f{s[u].y, s[u].y} - py[p];
-          dz[u][p] = v2f{s[u].z, s[u].z} - pz[p];
+          dz[u][p] = (UNIFORM ? v2f{s[u].z, s[u].w} : v2f{s[u].z, s[u].z}) - pz[p];
         }
 #pragma unroll
       for (int u = 0; u < U; ++u)

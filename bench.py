@@ -57,9 +57,9 @@ EXECUTED_FLOP_SYM = 12.0           # pair-symmetric kernels: 24 per unordered pa
 
 def measured_traffic():
     """HBM bytes per accel launch from the committed rocprofv3 PMC passes of THIS command (tools/profile.sh ->
-    profiles/r03_bench_n1_uniform_rocprofv3_summary.txt: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE). bench.py
+    profiles/r04_bench_n1_uniform_rocprofv3_summary.txt: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE). bench.py
     cannot run the profiler around itself, so the number is the profile's, or None if the file is absent."""
-    f = ROOT / "profiles" / "r03_bench_n1_uniform_rocprofv3_summary.txt"
+    f = ROOT / "profiles" / "r04_bench_n1_uniform_rocprofv3_summary.txt"
     try:
         rd = wr = None
         for line in f.read_text().splitlines():
@@ -651,7 +651,7 @@ def main():
                          "pair_symmetry": bool(symmetric),
                          "pair_symmetry_scope": (None if not symmetric else "every launch" if sym_all else "own-chunk launch of each rank only"),
                          "schedule": (None if world == 1 else "pair-symmetric: each pair of chunks worked on by one owner, partial sums returned" if best["pairwise"] else "one-sided: every rank sums all chunks for its own sinks"),
-                         "pair_terms_evaluated_per_launch_approx": (k_inter / 2.0 if sym_all else k_inter),   # PMC count (one v_rsq per term): profiles/r03_*_rocprofv3_summary.txt
+                         "pair_terms_evaluated_per_launch_approx": (k_inter / 2.0 if sym_all else k_inter),   # PMC count (one v_rsq per term): profiles/r04_*_rocprofv3_summary.txt
                          "executed_flop_per_interaction": EXECUTED_FLOP_SYM if sym_all else EXECUTED_FLOP_ONE_SIDED,
                          "frac_executed_flops": achieved / peak * (EXECUTED_FLOP_SYM if sym_all else EXECUTED_FLOP_ONE_SIDED) / FLOP_PER_INTERACTION,
                          "interactions_per_launch": k_inter, "avg_launch_ms": k_ms, "launches_timed": k_count,
