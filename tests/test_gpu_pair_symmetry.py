@@ -366,3 +366,50 @@ def test_symmetric_kernel_matches_committed_golden_vectors(name):
         assert e.last_accel_symmetric()
     err = rel_err(a[g[f"{name}_idx"]], g[f"{name}_acc"])
     assert err.max() < tol(dtype, n), f"{name}: {err.max():.3e}"
+
+
+BLOCKS_CODE = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import bachelor_thesis_n_body_amd as nb
+for dtype in (np.float32, np.float64):
+    for n, general in ((40000, False), (70001, True)):
+        s = nb.plummer_sphere(n, 13, dtype)
+        if general:
+            s = nb.State(s.pos, s.vel, (s.mass * np.random.default_rng(3).uniform(0.5, 2.0, n)).astype(dtype))
+        with nb.Engine(n, dtype) as e:
+            e.set_state(s)
+            a = e.accel(0.01)
+            assert e.last_accel_symmetric()
+            k, u = e.step_with_energy(0.0, 1, 0.01)
+        np.save(sys.argv[1] + "/a_%%s_%%d.npy" %% (np.dtype(dtype).name, n), a)
+        np.save(sys.argv[1] + "/u_%%s_%%d.npy" %% (np.dtype(dtype).name, n), np.array([u[0]]))
+print("done")
+"""
+
+
+@pytest.mark.parametrize("blocks", [1, 7, 333, 1000, 5001])
+def test_any_block_count_gives_the_same_sums(blocks, tmp_path):
+    """The equal-share deal of steps to blocks (accel_sym_*.hip) for block counts the built-in rule never picks — one block, a prime, counts that
+    cut almost every tile, more blocks than tiles have steps to spare: the same pair terms, so the same accelerations and potential to the
+    rounding of another summation order. (NB_F32_SYM_BLOCKS / NB_F64_SYM_BLOCKS are read once per process: child processes.)"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parent.parent)
+    res = {}
+    for tag, env_blocks in (("default", "0"), ("forced", str(blocks))):
+        d = tmp_path / tag
+        d.mkdir()
+        env = dict(os.environ, NB_F32_SYM_BLOCKS=env_blocks, NB_F64_SYM_BLOCKS=env_blocks)
+        out = subprocess.run([sys.executable, "-c", BLOCKS_CODE % root, str(d)], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "done" in out.stdout, out.stderr[-2000:]
+        res[tag] = {f.name: np.load(f) for f in d.glob("*.npy")}
+    for name, ref in res["default"].items():
+        got = res["forced"][name]
+        f32 = "float32" in name
+        if name.startswith("a_"):
+            assert rel_err(got, ref.astype(np.float64)).max() < (1e-6 if f32 else 1e-13), name
+        else:
+            assert abs(got[0] / ref[0] - 1) < (1e-7 if f32 else 1e-14), name
