@@ -171,7 +171,8 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
   // Two blocks share a CU (one wave of each per SIMD) and the issue arbiter prefers the OLDER wave: of two co-resident blocks with equal
   // work the first-dispatched finishes far ahead (325 against 774 us at N = 65 536) and the other then runs alone at ~70 % of the issue rate
   // two waves reach — the tail of a one-round launch. Letting the waves take turns at s_setprio (by their own step count, or by time slices
-  // of the constant-rate counter) was built and measured: no gain (profiles/r04_priority_turns_between_coresident_waves_negative_result.txt).
+  // of the constant-rate counter) was built and measured: no gain (profiles/r04_priority_turns_between_coresident_waves_negative_result.txt);
+  // nor does pinning the step's LDS reads above its arithmetic make a lone wave faster (same file, last block).
 
   auto walk = [&](auto symtag, int t_lo, int t_hi) {
     constexpr bool SYM = decltype(symtag)::value;
