@@ -76,7 +76,7 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
                      int n, int nsets, int H, int o_begin, int tps, long long G, float eps2,
                      double* __restrict__ part, float* __restrict__ slab, float* __restrict__ bslab, size_t n_pad,
                      const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs, const float* __restrict__ ms,
-                     int n_src, int nsets_src, size_t n_pad_src, int cross, int b0, long long* __restrict__ trace) {
+                     int n_src, int nsets_src, size_t n_pad_src, int cross, int b0, int turn_shift, long long* __restrict__ trace) {
   // trace (debugging aid, normally null; NB_SYM_TRACE=<file>): [block][start tick, end tick, HW_ID | XCC_ID << 32] of the constant-rate counter
   // cross = 0: the set (x, y, z, m) on itself (xs.. are the same arrays). cross = 1: block A = (x..) against a DIFFERENT block B = (xs..):
   // sink set b of A walks every set of B two-sidedly (o = 0 .. nsets_src - 1 -> set (b + o) mod nsets_src); B's sums go to slab slot
@@ -168,11 +168,19 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
 
   const float4* tl = tile + lane;
   float* ac = &acc[wv][0][lane * AW];
-  // Two blocks share a CU (one wave of each per SIMD) and the issue arbiter prefers the OLDER wave: of two co-resident blocks with equal
-  // work the first-dispatched finishes far ahead (325 against 774 us at N = 65 536) and the other then runs alone at ~70 % of the issue rate
-  // two waves reach — the tail of a one-round launch. Letting the waves take turns at s_setprio (by their own step count, or by time slices
-  // of the constant-rate counter) was built and measured: no gain (profiles/r04_priority_turns_between_coresident_waves_negative_result.txt);
-  // nor does pinning the step's LDS reads above its arithmetic make a lone wave faster (same file, last block).
+  // Two blocks share a CU (one wave of each per SIMD) and the issue arbiter prefers the OLDER wave whenever both are ready (MI355X_MICROARCH.md:
+  // "priority, then age"): of two co-resident blocks with equal work the first-dispatched runs at 0.75 of the SIMD's issue rate, the other
+  // at 0.22, and once the first has ended the second continues alone at the 0.8-0.9 a lone wave reaches (measured with NB_SYM_TRACE at
+  // N = 65 536: 462 against 764 us per CU; a lone wave per SIMD over a whole launch: 0.81 / 0.90 of the two-wave rate at N = 65 536 / 2^20) —
+  // the pair finishes 10 % later than two waves sharing fairly would. So the two waves take TURNS at the raised priority: time slices of
+  // 2^turn_shift ticks of the constant-rate counter (100 MHz, the same for every wave of the device), the wave whose slot id has the slice's
+  // parity runs at s_setprio 1, the other at 0. The counter is read when a chunk of 8 steps begins and acted on when it ends (scalar work
+  // outside the step loop). The slice must be long against that look-up period: 2^14 ticks = 164 us (per CU 667 against 727 us, launch 819 ->
+  // 776 us; 2^12: 613 / 742). First attempts failed for exactly that reason — turns counted in each wave's OWN steps let the leader reach
+  // its next favoured segment first (63 : 37), slices of 10 us looked at every 32 steps (~20-40 us) left the two priorities uncorrelated
+  // (profiles/r04_priority_turns_between_coresident_waves.txt). Pinning the step's LDS reads above its arithmetic does not make a lone wave faster.
+  unsigned slot_id;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(slot_id));      // wave slot within its SIMD
 
   auto walk = [&](auto symtag, int t_lo, int t_hi) {
     constexpr bool SYM = decltype(symtag)::value;
@@ -263,7 +271,13 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
     float4 sa[U], sb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) sa[u] = ld_src<UNIFORM>(tl + t_lo + u * HS);
-    for (int t = t_lo; t < t_hi; t += 2) { step(sa, sb, t); step(sb, sa, t + 1); }
+    for (int tc = t_lo; tc < t_hi; tc += 8) {
+      const int te = tc + 8 < t_hi ? tc + 8 : t_hi;
+      unsigned long long now = 0;
+      if (turn_shift > 0) now = __builtin_amdgcn_s_memrealtime();
+      for (int t = tc; t < te; t += 2) { step(sa, sb, t); step(sb, sa, t + 1); }
+      if (turn_shift > 0) { if (((now >> turn_shift) ^ slot_id) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    }
 #pragma unroll
     for (int p = 0; p < KP; ++p) {
       tx[2 * p] += (double)fx[p].x; ty[2 * p] += (double)fy[p].x; tz[2 * p] += (double)fz[p].x;
@@ -403,10 +417,12 @@ int sym_blocks(nb_ctx* c, K kernel, long long tiles, long long env_blocks, long 
     slots = (long long)per_cu * cus;
     cache.push_back(Slot{(const void*)kernel, c->device, slots});
   }
-  // rounds: 1 would be the static optimum if every slot ran at the same speed; measured (profiles/r04_sym_block_shares_ab.txt, N = 2^20, one
-  // box) 163.4 ms with 1 round, 160.0 / 158.8 / 157.6 with 2 / 4 / 8: the slots do NOT run equally fast, and shares an eighth the size let
-  // the dispatcher even that out. Small launches keep >= 4 tiles per block (at N = 65 536 the round count makes no measurable difference).
-  const long long rounds = env_rounds > 0 ? env_rounds : std::min<long long>(8, std::max<long long>(1, tiles / (4 * slots)));
+  // rounds: 1 is the static optimum when every slot runs at the same speed. Before the co-resident waves took turns at the issue priority
+  // (see the kernel) they did not — 163.4 ms with 1 round, 160.0 / 158.8 / 157.6 with 2 / 4 / 8 at N = 2^20 — and finer shares let the
+  // dispatcher even that out; with the turns the round count hardly matters at N = 2^20 (157.9 - 158.7 ms for 1 ... 8) and ONE round is
+  // 1 - 2.5 % faster up to N ~ 500 000 (profiles/r04_sym_rounds_sweep_with_priority_turns.txt). What finer shares still buy on large launches
+  // is tolerance of the XCDs' clocks (3.5 - 5 % apart on one board): from 128 tiles per slot on, up to 8 rounds.
+  const long long rounds = env_rounds > 0 ? env_rounds : std::min<long long>(8, std::max<long long>(1, tiles / (128 * slots)));
   long long nblk = env_blocks > 0 ? env_blocks : slots * rounds;
   if (nblk > tiles) nblk = tiles;
   if (nblk > 65535 * 16) nblk = 65535 * 16;
@@ -424,7 +440,7 @@ auto sym_kernel(bool guard, bool uniform) {
 
 template <int KS, int U, bool POT>
 int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const float* m, int64_t n,
-            float eps2, float G, float* ax, float* ay, float* az, int flags, long long budget, long long env_blocks, long long env_rounds, double* phi) {
+            float eps2, float G, float* ax, float* ay, float* az, int flags, long long budget, long long env_blocks, long long env_rounds, int turn_shift, double* phi) {
   constexpr int TJ = POT ? 256 : 512, SET = BLOCK * KS, NC = POT ? 4 : 3;   // POT: a fourth accumulator per source — half the tile keeps the LDS footprint
   constexpr int QT = SET / TJ, HS = TJ / U;                  // tiles per set, steps per tile
   const int nsets = (int)((n + SET - 1) / SET);
@@ -476,7 +492,7 @@ int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const flo
     long long* trace = nullptr;
     if (trace_path && *trace_path) NB_HIP(c, hipMalloc(&trace, (size_t)nblk * 3 * sizeof(long long)));
     kernel<<<nblk, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, nsets, H, o_begin, tps, Gs, eps2, part, slab, bslab, n_pad,
-                                          x, y, z, m, (int)n, nsets, n_pad, 0, 0, trace);
+                                          x, y, z, m, (int)n, nsets, n_pad, 0, 0, turn_shift, trace);
     NB_HIP(c, hipGetLastError());
     if (trace) {
       std::vector<long long> h((size_t)nblk * 3);
@@ -505,7 +521,7 @@ template <int KS, int U, bool POT>
 int run_cross(nb_ctx* c, const float* xa, const float* ya, const float* za, const float* ma, int64_t na,
               const float* xb, const float* yb, const float* zb, const float* mb, int64_t nb,
               float eps2, float G, float* aax, float* aay, float* aaz, float* bax, float* bay, float* baz,
-              double* phi_a, double* phi_b, int flags, long long budget, long long env_blocks, long long env_rounds) {
+              double* phi_a, double* phi_b, int flags, long long budget, long long env_blocks, long long env_rounds, int turn_shift) {
   constexpr int TJ = POT ? 256 : 512, SET = BLOCK * KS, NC = POT ? 4 : 3;
   constexpr int QT = SET / TJ, HS = TJ / U;
   const int nsa = (int)((na + SET - 1) / SET), nsb = (int)((nb + SET - 1) / SET);
@@ -540,7 +556,7 @@ int run_cross(nb_ctx* c, const float* xa, const float* ya, const float* za, cons
     const int nb_launch = std::min(nblk_max, sym_blocks(c, kernel, (long long)nb_sets * tps, env_blocks, env_rounds));
     if (nb_launch / nb_sets + 2 > nseg_max) return nb_fail(c, NB_ERR_ARG, "accel_sym_f32: internal slot count");
     kernel<<<nb_launch, BLOCK, 0, c->stream>>>(xa, ya, za, ma, (int)na, nsa, 0, 0, tps, Gs, eps2, part, slab, bslab, npa,
-                                               xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0, nullptr);
+                                               xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0, turn_shift, nullptr);
     NB_HIP(c, hipGetLastError());
     accel_sym_boundary_f32_kernel<KS, U, TJ, POT><<<nb_launch, BLOCK, 0, c->stream>>>(slab, bslab, nsa, 0, 0, tps, Gs, nsb, npb, 1, b0);
     NB_HIP(c, hipGetLastError());
@@ -559,13 +575,14 @@ int run_cross(nb_ctx* c, const float* xa, const float* ya, const float* za, cons
 }
 
 // options of the pair-symmetric kernels: the context's (nb_set_option) or, where unset, the process-wide defaults from the environment
-struct SymOpt { long long mode, min_n, budget, blocks, rounds, ks; };
+struct SymOpt { long long mode, min_n, budget, blocks, rounds, ks, turn; };
 SymOpt sym_options(const nb_ctx* c) {
   static const long long env_mode = env_ll("NB_F32_SYM", 1), env_min_n = env_ll("NB_F32_SYM_MIN_N", 24576),
                          env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_blocks = env_ll("NB_F32_SYM_BLOCKS", 0),
-                         env_rounds = env_ll("NB_F32_SYM_ROUNDS", 0), env_ks = env_ll("NB_F32_SYM_KS", 0);
+                         env_rounds = env_ll("NB_F32_SYM_ROUNDS", 0), env_ks = env_ll("NB_F32_SYM_KS", 0),
+                         env_turn = env_ll("NB_F32_SYM_TURN_SHIFT", 14);     // priority turns: time slices of 2^14 ticks of the 100 MHz counter (164 us); 0 = off
   return SymOpt{c->sym_enable >= 0 ? c->sym_enable : env_mode, c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
-                c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_blocks, env_rounds, env_ks};
+                c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_blocks, env_rounds, env_ks, env_turn};
 }
 
 }  // namespace
@@ -589,7 +606,7 @@ int nb_launch_accel_sym_f32(nb_ctx* c, const float* x, const float* y, const flo
   if (ks == 12 && items(12, tj) < 3300) ks = 8;
   if (ks == 8 && items(8, tj) < 700) ks = 4;
   if (env_ks == 4 || env_ks == 8 || (env_ks == 12 && (flags & NB_UNIFORM_MASS) && !phi)) ks = (int)env_ks;
-#define NB_RUN(K, UU, PT) run_sym<K, UU, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, opt.blocks, opt.rounds, phi)
+#define NB_RUN(K, UU, PT) run_sym<K, UU, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, opt.blocks, opt.rounds, (int)opt.turn, phi)
   const int rc = phi ? (ks == 8 ? NB_RUN(8, 1, true) : NB_RUN(4, 2, true))
                      : (ks == 12 ? NB_RUN(12, 1, false) : ks == 8 ? NB_RUN(8, 2, false) : NB_RUN(4, 2, false));
 #undef NB_RUN
@@ -617,7 +634,7 @@ int nb_launch_accel_cross_f32(nb_ctx* c, const float* xa, const float* ya, const
   int ks = (flags & NB_UNIFORM_MASS) && !pot ? 12 : 8;      // as for a set on itself (nb_launch_accel_sym_f32)
   if (ks == 12 && items(12) < 3300) ks = 8;
   if (ks == 8 && items(8) < 700) ks = 4;
-#define NB_RUN(K, UU, PT) run_cross<K, UU, PT>(c, xa, ya, za, ma, na, xb, yb, zb, mb, nb, eps2, G, aax, aay, aaz, bax, bay, baz, phi_a, phi_b, flags, budget, opt.blocks, opt.rounds)
+#define NB_RUN(K, UU, PT) run_cross<K, UU, PT>(c, xa, ya, za, ma, na, xb, yb, zb, mb, nb, eps2, G, aax, aay, aaz, bax, bay, baz, phi_a, phi_b, flags, budget, opt.blocks, opt.rounds, (int)opt.turn)
   const int rc = pot ? (ks == 8 ? NB_RUN(8, 1, true) : NB_RUN(4, 2, true))
                      : (ks == 12 ? NB_RUN(12, 1, false) : ks == 8 ? NB_RUN(8, 2, false) : NB_RUN(4, 2, false));
 #undef NB_RUN

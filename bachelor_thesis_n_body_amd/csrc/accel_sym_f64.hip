@@ -52,7 +52,7 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
                      int n, int nsets, int H, int o_begin, int tps, long long G, double eps2,
                      double* __restrict__ part, double* __restrict__ slab, double* __restrict__ bslab, size_t n_pad,
                      const double* __restrict__ xs, const double* __restrict__ ys, const double* __restrict__ zs, const double* __restrict__ ms,
-                     int n_src, int nsets_src, size_t n_pad_src, int cross, int b0) {
+                     int n_src, int nsets_src, size_t n_pad_src, int cross, int b0, int turn_shift) {
   // cross = 0: the set on itself (xs.. are the same arrays); cross = 1: block A = (x..) against a different block B = (xs..), every A-B pair
   // two-sided, B's sums to slab slot b - b0 (see accel_sym_f32.hip). The launch's steps g = ((bb * tps + tau) * TJ + t) are dealt to the
   // blocks in equal shares; a tile cut by a block boundary leaves the second block's share in the bslab.
@@ -126,6 +126,9 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
 
   const d4* tl = tile + lane;
   double* ac = &acc[wv][0][lane];
+  // the two co-resident waves of a SIMD take turns at the raised issue priority in time slices of the constant-rate counter (accel_sym_f32.hip)
+  unsigned slot_id;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(slot_id));
 
   auto walk = [&](auto symtag, int t_lo, int t_hi) {
     constexpr bool SYM = decltype(symtag)::value;
@@ -161,7 +164,13 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
       }
     };
     d4 sa = ld_src<UNIFORM>(tl + t_lo), sb;
-    for (int t = t_lo; t < t_hi; t += 2) { step(sa, sb, t); step(sb, sa, t + 1); }
+    for (int tc = t_lo; tc < t_hi; tc += 8) {
+      const int te = tc + 8 < t_hi ? tc + 8 : t_hi;
+      unsigned long long now = 0;
+      if (turn_shift > 0) now = __builtin_amdgcn_s_memrealtime();
+      for (int t = tc; t < te; t += 2) { step(sa, sb, t); step(sb, sa, t + 1); }
+      if (turn_shift > 0) { if (((now >> turn_shift) ^ slot_id) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    }
   };
 
   int cur = -1, seg = 0;
@@ -286,10 +295,12 @@ int sym_blocks(nb_ctx* c, K kernel, long long tiles, long long env_blocks, long 
     slots = (long long)per_cu * cus;
     cache.push_back(Slot{(const void*)kernel, c->device, slots});
   }
-  // rounds: 1 would be the static optimum if every slot ran at the same speed; measured (profiles/r04_sym_block_shares_ab.txt, N = 2^20, one
-  // box) 163.4 ms with 1 round, 160.0 / 158.8 / 157.6 with 2 / 4 / 8: the slots do NOT run equally fast, and shares an eighth the size let
-  // the dispatcher even that out. Small launches keep >= 4 tiles per block (at N = 65 536 the round count makes no measurable difference).
-  const long long rounds = env_rounds > 0 ? env_rounds : std::min<long long>(8, std::max<long long>(1, tiles / (4 * slots)));
+  // rounds: 1 is the static optimum when every slot runs at the same speed. Before the co-resident waves took turns at the issue priority
+  // (see the kernel) they did not — 163.4 ms with 1 round, 160.0 / 158.8 / 157.6 with 2 / 4 / 8 at N = 2^20 — and finer shares let the
+  // dispatcher even that out; with the turns the round count hardly matters at N = 2^20 (157.9 - 158.7 ms for 1 ... 8) and ONE round is
+  // 1 - 2.5 % faster up to N ~ 500 000 (profiles/r04_sym_rounds_sweep_with_priority_turns.txt). What finer shares still buy on large launches
+  // is tolerance of the XCDs' clocks (3.5 - 5 % apart on one board): from 128 tiles per slot on, up to 8 rounds.
+  const long long rounds = env_rounds > 0 ? env_rounds : std::min<long long>(8, std::max<long long>(1, tiles / (128 * slots)));
   long long nblk = env_blocks > 0 ? env_blocks : slots * rounds;
   if (nblk > tiles) nblk = tiles;
   if (nblk > 65535 * 16) nblk = 65535 * 16;
@@ -304,7 +315,7 @@ auto sym_kernel(bool guard, bool uniform) {
 
 template <int KS, bool POT>
 int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const double* m, int64_t n,
-            double eps2, double G, double* ax, double* ay, double* az, int flags, long long budget, long long env_blocks, long long env_rounds, double* phi) {
+            double eps2, double G, double* ax, double* ay, double* az, int flags, long long budget, long long env_blocks, long long env_rounds, int turn_shift, double* phi) {
   constexpr int TJ = 256, SET = BLOCK * KS, NC = POT ? 4 : 3;
   constexpr int QT = SET / TJ, HS = TJ;
   const int nsets = (int)((n + SET - 1) / SET);
@@ -348,7 +359,7 @@ int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const 
     const int nslots = std::max(0, s_end - s_begin);
     if (nblk / nsets + 2 > nseg_max) return nb_fail(c, NB_ERR_ARG, "accel_sym_f64: internal slot count");
     kernel<<<nblk, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, nsets, H, o_begin, tps, Gs, eps2, part, slab, bslab, n_pad,
-                                          x, y, z, m, (int)n, nsets, n_pad, 0, 0);
+                                          x, y, z, m, (int)n, nsets, n_pad, 0, 0, turn_shift);
     NB_HIP(c, hipGetLastError());
     accel_sym_boundary_f64_kernel<KS, TJ, POT><<<nblk, BLOCK, 0, c->stream>>>(slab, bslab, nsets, H, o_begin, tps, Gs, nsets, n_pad, 0, 0);
     NB_HIP(c, hipGetLastError());
@@ -365,7 +376,7 @@ template <int KS, bool POT>
 int run_cross(nb_ctx* c, const double* xa, const double* ya, const double* za, const double* ma, int64_t na,
               const double* xb, const double* yb, const double* zb, const double* mb, int64_t nb,
               double eps2, double G, double* aax, double* aay, double* aaz, double* bax, double* bay, double* baz,
-              double* phi_a, double* phi_b, int flags, long long budget, long long env_blocks, long long env_rounds) {
+              double* phi_a, double* phi_b, int flags, long long budget, long long env_blocks, long long env_rounds, int turn_shift) {
   constexpr int TJ = 256, SET = BLOCK * KS, NC = POT ? 4 : 3;
   constexpr int QT = SET / TJ, HS = TJ;
   const int nsa = (int)((na + SET - 1) / SET), nsb = (int)((nb + SET - 1) / SET);
@@ -400,7 +411,7 @@ int run_cross(nb_ctx* c, const double* xa, const double* ya, const double* za, c
     const int nb_launch = std::min(nblk_max, sym_blocks(c, kernel, (long long)nb_sets * tps, env_blocks, env_rounds));
     if (nb_launch / nb_sets + 2 > nseg_max) return nb_fail(c, NB_ERR_ARG, "accel_sym_f64: internal slot count");
     kernel<<<nb_launch, BLOCK, 0, c->stream>>>(xa, ya, za, ma, (int)na, nsa, 0, 0, tps, Gs, eps2, part, slab, bslab, npa,
-                                               xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0);
+                                               xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0, turn_shift);
     NB_HIP(c, hipGetLastError());
     accel_sym_boundary_f64_kernel<KS, TJ, POT><<<nb_launch, BLOCK, 0, c->stream>>>(slab, bslab, nsa, 0, 0, tps, Gs, nsb, npb, 1, b0);
     NB_HIP(c, hipGetLastError());
@@ -417,13 +428,13 @@ int run_cross(nb_ctx* c, const double* xa, const double* ya, const double* za, c
 }
 
 // options of the pair-symmetric kernels: the context's (nb_set_option) or, where unset, the process-wide defaults from the environment
-struct SymOpt { long long mode, min_n, budget, blocks, rounds, ks; };
+struct SymOpt { long long mode, min_n, budget, blocks, rounds, ks, turn; };
 SymOpt sym_options(const nb_ctx* c) {
   static const long long env_mode = env_ll("NB_F64_SYM", 1), env_min_n = env_ll("NB_F64_SYM_MIN_N", 16384),
                          env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_blocks = env_ll("NB_F64_SYM_BLOCKS", 0),
-                         env_rounds = env_ll("NB_F64_SYM_ROUNDS", 0), env_ks = env_ll("NB_F64_SYM_KS", 0);
+                         env_rounds = env_ll("NB_F64_SYM_ROUNDS", 0), env_ks = env_ll("NB_F64_SYM_KS", 0), env_turn = env_ll("NB_F64_SYM_TURN_SHIFT", 14);
   return SymOpt{c->sym_enable >= 0 ? c->sym_enable : env_mode, c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
-                c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_blocks, env_rounds, env_ks};
+                c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_blocks, env_rounds, env_ks, env_turn};
 }
 
 }  // namespace
@@ -443,7 +454,7 @@ int nb_launch_accel_sym_f64(nb_ctx* c, const double* x, const double* y, const d
   if (items(8) < 1000) ks = 4;
   if (ks == 4 && items(4) < 1000) ks = 2;
   if (env_ks == 2 || env_ks == 4 || env_ks == 8) ks = (int)env_ks;
-#define NB_RUN(K, PT) run_sym<K, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, opt.blocks, opt.rounds, phi)
+#define NB_RUN(K, PT) run_sym<K, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, opt.blocks, opt.rounds, (int)opt.turn, phi)
   const int rc = phi ? (ks == 8 ? NB_RUN(8, true) : ks == 4 ? NB_RUN(4, true) : NB_RUN(2, true))
                      : (ks == 8 ? NB_RUN(8, false) : ks == 4 ? NB_RUN(4, false) : NB_RUN(2, false));
 #undef NB_RUN
@@ -469,7 +480,7 @@ int nb_launch_accel_cross_f64(nb_ctx* c, const double* xa, const double* ya, con
   int ks = 8;
   if (items(8) < 1000) ks = 4;
   if (ks == 4 && items(4) < 1000) ks = 2;
-#define NB_RUN(K, PT) run_cross<K, PT>(c, xa, ya, za, ma, na, xb, yb, zb, mb, nb, eps2, G, aax, aay, aaz, bax, bay, baz, phi_a, phi_b, flags, budget, opt.blocks, opt.rounds)
+#define NB_RUN(K, PT) run_cross<K, PT>(c, xa, ya, za, ma, na, xb, yb, zb, mb, nb, eps2, G, aax, aay, aaz, bax, bay, baz, phi_a, phi_b, flags, budget, opt.blocks, opt.rounds, (int)opt.turn)
   const int rc = pot ? (ks == 8 ? NB_RUN(8, true) : ks == 4 ? NB_RUN(4, true) : NB_RUN(2, true))
                      : (ks == 8 ? NB_RUN(8, false) : ks == 4 ? NB_RUN(4, false) : NB_RUN(2, false));
 #undef NB_RUN
