@@ -93,6 +93,7 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
   __shared__ float4 tile[AS];
   constexpr int AW = 2;              // the two halves of a packed partial sum keep separate accumulators (no add per step)
   __shared__ float acc[WAVES][NC][AS * AW];
+  __shared__ unsigned turn_slots[WAVES];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float far = 1e20f;           // UNIFORM padding: r^2 overflows to +inf, v_rsq_f32(+inf) = +0, every term exactly 0
@@ -163,6 +164,9 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
     if (tid < 64) tile[TJ + tid] = stage[0];       // wrap-around copies of entries 0..63
   };
 
+  unsigned wave_slot;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(wave_slot));      // wave slot within its SIMD: the block's turn id below
+  if (lane == 0) turn_slots[wv] = wave_slot;
   if (g_begin < g_end) { fetch(g_begin / HS); commit(); }
   __syncthreads();
 
@@ -179,8 +183,14 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
   // 776 us; 2^12: 613 / 742). First attempts failed for exactly that reason — turns counted in each wave's OWN steps let the leader reach
   // its next favoured segment first (63 : 37), slices of 10 us looked at every 32 steps (~20-40 us) left the two priorities uncorrelated
   // (profiles/r04_priority_turns_between_coresident_waves.txt). Pinning the step's LDS reads above its arithmetic does not make a lone wave faster.
-  unsigned slot_id;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(slot_id));      // wave slot within its SIMD
+  // The turn is the BLOCK's, not the wave's: all four waves of a block must be favoured in the same slices (they meet at every tile's barrier,
+  // so a block runs at the pace of its slowest wave). The block's id for the turns is the smallest wave-slot id among its waves: where the
+  // CU holds nothing else that is 0 for the first block and 1 for the second on every SIMD; where a third wave sits on one SIMD (bench.py's
+  // clock probe: one sleeping wave per XCD) the per-wave ids there are 1 and 2 against 0 and 1 elsewhere, and per-WAVE turns put one wave of
+  // each block out of phase with its three partners — that CU then straggled by 6 % and, under a deal with few rounds, so did the launch
+  // (bench.py with the probe: +4-8 %; without: -3 % ... 0; profiles/r04_priority_turns_between_coresident_waves.txt).
+  unsigned slot_id = min(min(turn_slots[0], turn_slots[1]), min(turn_slots[2], turn_slots[3]));
+  slot_id = __builtin_amdgcn_readfirstlane(slot_id);
 
   auto walk = [&](auto symtag, int t_lo, int t_hi) {
     constexpr bool SYM = decltype(symtag)::value;
@@ -417,12 +427,14 @@ int sym_blocks(nb_ctx* c, K kernel, long long tiles, long long env_blocks, long 
     slots = (long long)per_cu * cus;
     cache.push_back(Slot{(const void*)kernel, c->device, slots});
   }
-  // rounds: 1 is the static optimum when every slot runs at the same speed. Before the co-resident waves took turns at the issue priority
-  // (see the kernel) they did not — 163.4 ms with 1 round, 160.0 / 158.8 / 157.6 with 2 / 4 / 8 at N = 2^20 — and finer shares let the
-  // dispatcher even that out; with the turns the round count hardly matters at N = 2^20 (157.9 - 158.7 ms for 1 ... 8) and ONE round is
-  // 1 - 2.5 % faster up to N ~ 500 000 (profiles/r04_sym_rounds_sweep_with_priority_turns.txt). What finer shares still buy on large launches
-  // is tolerance of the XCDs' clocks (3.5 - 5 % apart on one board): from 128 tiles per slot on, up to 8 rounds.
-  const long long rounds = env_rounds > 0 ? env_rounds : std::min<long long>(8, std::max<long long>(1, tiles / (128 * slots)));
+  // rounds: 1 is the static optimum when every slot runs at the same speed. They do not: the XCDs of one board hold clocks 3.5 - 6 % apart, and
+  // under a static deal the slowest XCD sets the launch time. Before the co-resident waves took turns at the issue priority (see the kernel) finer
+  // shares also evened out the unfair sharing of a CU (N = 2^20: 163.4 ms with 1 round, 160.0 / 158.8 / 157.6 with 2 / 4 / 8). With the turns: on a
+  // box whose XCDs differ by 2 % the round count hardly matters at N = 2^20 (157.9 - 158.7 ms for 1 ... 8) and one round is 1 - 2.5 % faster up
+  // to N ~ 500 000 (profiles/r04_sym_rounds_sweep_with_priority_turns.txt); on a box whose XCDs differ by 6 % five rounds at N = 2^20 cost 5 %
+  // against the eight of the record before (profiles/r04_bench_n1_driver_form_5_rounds_6pct_xcd_spread.json). So: as many rounds as leave 16
+  // tiles per block, at most 8 — large launches tolerate the clock spread, small ones keep their few tiles whole.
+  const long long rounds = env_rounds > 0 ? env_rounds : std::min<long long>(8, std::max<long long>(1, tiles / (16 * slots)));
   long long nblk = env_blocks > 0 ? env_blocks : slots * rounds;
   if (nblk > tiles) nblk = tiles;
   if (nblk > 65535 * 16) nblk = 65535 * 16;

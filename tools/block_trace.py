@@ -14,7 +14,11 @@ for n in [int(v) for v in sys.argv[1:]] or [65536]:
     with nb.Engine(n, np.float32) as e:
         e.set_state(nb.plummer_sphere(n, 0, np.float32))
         e.accel(0.01, fetch=False)
+        probe = nb.ClockProbe(0, 3000.0) if os.environ.get("BLOCK_TRACE_PROBE") else None      # the bench's clock probe beside the launch: one sleeping wave per XCD
         e.accel(0.01, fetch=False)
+        if probe is not None:
+            probe.stop(0)
+            print("  clock probe beside the launch:", [round(v) for v in probe.end_xcd()[2]])
     launches, cur = [], None
     for line in open(path):
         if line.startswith("#"):
@@ -53,6 +57,10 @@ for n in [int(v) for v in sys.argv[1:]] or [65536]:
         print(f"  CUs whose two blocks started together: {len(pairs)}; shorter of the two mean {np.minimum(d0, d1).mean():.1f} us, longer mean {np.maximum(d0, d1).mean():.1f} us; "
               f"wave slots (first, second block): {sorted(collections.Counter((p[0][2], p[1][2]) for p in pairs).items())}; SIMD of wave 0: {sorted(collections.Counter((p[0][3], p[1][3]) for p in pairs).items())}")
         print("  first five pairs (start, duration, slot, simd):", pairs[:5])
+    # the slowest CUs (sum of their blocks' durations): does a disturbance sit on a few CUs?
+    per_cu = sorted(((sum(v[1] for v in vs), k) for k, vs in by_cu.items()), reverse=True)
+    print("  CU busy time (sum of its blocks' durations) max / median / min: %.1f / %.1f / %.1f us; the 10 busiest CUs (xcd, se, sh, cu): %s" % (
+        per_cu[0][0], per_cu[len(per_cu) // 2][0], per_cu[-1][0], [k for _, k in per_cu[:10]]))
     late = start > 0.2 * end.max()
     print(f"  blocks that started after 20 % of the makespan: {late.sum()}")
     order = np.argsort(end)
