@@ -63,6 +63,9 @@ SIGNATURES = {
     "nb_kinetic_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _i64, _vp]),
     "nb_kick_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl]),
     "nb_drift_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl]),
+    "nb_kick_drift_dev": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl]),
+    "nb_accel_kdk_dev": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _int,
+                                _vp, _vp, _vp, _dbl, _dbl, _dbl]),
 }
 
 _lib = None

@@ -366,20 +366,32 @@ accel_sym_boundary_f32_kernel(float* __restrict__ slab, const float* __restrict_
     for (int e = threadIdx.x; e < TJ; e += BLOCK) sl[(size_t)cc * n_pad_src + e] += bs[cc * TJ + e];
 }
 
+// What the reduce kernel needs to finish the tiles that a block boundary cut (self launches; bslab = nullptr: nothing to finish, or the
+// separate boundary kernel above has run), and the integrator tail it may apply to the particles it completes (vx = nullptr: none).
+struct SymCut { const float* bslab; int nsets, o_begin, s_begin, tps, tj, hs; };
+struct SymTail { float *vx, *vy, *vz, *x, *y, *z; float kick_close, kick_open, drift; int advance; };
+
 // a[c][i] (+)= g * ( sum_seg part[seg][c][i] + sum_s slab[s][c][i] ), fixed order; `tot` non-null: the sums of several passes are collected in
 // fp64 first (first: tot = sum, otherwise tot += sum) and turned into accelerations by the last pass. The part slots of a particle are those of
 // the blocks that shared its sink set (part_block_of: the same function of (G, nblk) the force kernel dealt its work by); nblk = 0: no part slab.
+// cut.bslab non-null: slab entry s of a particle lacks the share of the block that STARTED inside its tile, if one did — block
+// part_block_of(first step of the tile) + 1 when that block begins before the tile ends; its row of the bslab is added here, in fp32 and before
+// the conversion, exactly as the boundary kernel would have (same bits). The 256 particles of a block of this kernel lie in one tile (sets and
+// tiles are multiples of 256), so the blocks are looked up once per slot by the first `nslots` threads and passed through LDS.
+// tail.vx non-null (last pass only): the leapfrog tail of nb_ctx::Tail on the particles this thread has just completed.
 __global__ void __launch_bounds__(256)
 accel_sym_reduce_f32_kernel(const double* __restrict__ part, long long G, int nblk, long long S, int set_size, int b0,
                             const float* __restrict__ slab, int nslots, int n, size_t n_pad,
                             float G_newton, const float* __restrict__ m0, double* __restrict__ tot, int first, int last,
                             float* __restrict__ ax, float* __restrict__ ay, float* __restrict__ az, int accumulate, double* __restrict__ phi,
-                            int i_begin) {
+                            int i_begin, SymCut cut, SymTail tail) {
+  __shared__ int cut_block[256];
   const int nc = phi ? 4 : 3;
-  const int i = i_begin + blockIdx.x * blockDim.x + threadIdx.x;      // particles [i_begin, n)
-  if (i >= n) return;
+  const int i0 = i_begin + blockIdx.x * blockDim.x;                    // particles [i_begin, n)
+  const int i = i0 + threadIdx.x;
+  const bool live = i < n;
   double sx = 0.0, sy = 0.0, sz = 0.0, sp = 0.0;
-  if (nblk > 0) {
+  if (live && nblk > 0) {
     const long long bb = i / set_size - b0;
     const int nseg = part_block_of((bb + 1) * S - 1, G, nblk) - part_block_of(bb * S, G, nblk) + 1;
     for (int g = 0; g < nseg; ++g) {
@@ -388,12 +400,46 @@ accel_sym_reduce_f32_kernel(const double* __restrict__ part, long long G, int nb
       if (phi) sp += p[3 * n_pad + i];
     }
   }
+  if (!cut.bslab) {
+    if (live) {
 #pragma unroll 8
-  for (int s = 0; s < nslots; ++s) {
-    const float* p = slab + (size_t)s * nc * n_pad;
-    sx += (double)p[i]; sy += (double)p[n_pad + i]; sz += (double)p[2 * n_pad + i];
-    if (phi) sp += (double)p[3 * n_pad + i];
+      for (int s = 0; s < nslots; ++s) {
+        const float* p = slab + (size_t)s * nc * n_pad;
+        sx += (double)p[i]; sy += (double)p[n_pad + i]; sz += (double)p[2 * n_pad + i];
+        if (phi) sp += (double)p[3 * n_pad + i];
+      }
+    }
+  } else {
+    const int c = i0 / set_size, r0 = i0 - c * set_size, q = r0 / cut.tj, e = r0 - q * cut.tj + (int)threadIdx.x;
+    for (int s0 = 0; s0 < nslots; s0 += 256) {
+      const int ns = nslots - s0 < 256 ? nslots - s0 : 256;
+      if (s0 > 0) __syncthreads();
+      if ((int)threadIdx.x < ns) {
+        const int o = cut.s_begin + s0 + (int)threadIdx.x;               // the offset of slot s; its sink set bb met this particle's set c
+        int bb = c - o; if (bb < 0) bb += cut.nsets;
+        const long long g0 = ((long long)bb * cut.tps + (long long)(o - cut.o_begin) * (set_size / cut.tj) + q) * cut.hs;
+        const int k0 = part_block_of(g0, G, nblk);
+        cut_block[threadIdx.x] = part_begin(k0 + 1, G, nblk) < g0 + cut.hs ? k0 + 1 : -1;
+      }
+      __syncthreads();
+      if (live) {
+#pragma unroll 4
+        for (int s = 0; s < ns; ++s) {
+          const float* p = slab + (size_t)(s0 + s) * nc * n_pad;
+          float vx = p[i], vy = p[n_pad + i], vz = p[2 * n_pad + i], vp = phi ? p[3 * n_pad + i] : 0.f;
+          const int kb = cut_block[s];
+          if (kb >= 0) {
+            const float* bs = cut.bslab + (size_t)kb * nc * cut.tj + e;
+            vx += bs[0]; vy += bs[cut.tj]; vz += bs[2 * cut.tj];
+            if (phi) vp += bs[3 * cut.tj];
+          }
+          sx += (double)vx; sy += (double)vy; sz += (double)vz;
+          if (phi) sp += (double)vp;
+        }
+      }
+    }
   }
+  if (!live) return;
   if (tot) {
     if (!first) { sx += tot[i]; sy += tot[(size_t)n + i]; sz += tot[2 * (size_t)n + i]; if (phi) sp += tot[3 * (size_t)n + i]; }
     if (!last) { tot[i] = sx; tot[(size_t)n + i] = sy; tot[2 * (size_t)n + i] = sz; if (phi) tot[3 * (size_t)n + i] = sp; return; }
@@ -403,6 +449,19 @@ accel_sym_reduce_f32_kernel(const double* __restrict__ part, long long G, int nb
   float ox = (float)(g * sx), oy = (float)(g * sy), oz = (float)(g * sz);
   if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
   ax[i] = ox; ay[i] = oy; az[i] = oz;
+  if (tail.vx) {                                            // as kick_kernel / kick_drift_kernel (integrate.hip): products and sums rounded one by one
+#pragma clang fp contract(off)
+    float v0 = tail.vx[i] + ox * tail.kick_close;
+    float v1 = tail.vy[i] + oy * tail.kick_close;
+    float v2 = tail.vz[i] + oz * tail.kick_close;
+    if (tail.advance) {
+      v0 = v0 + ox * tail.kick_open; v1 = v1 + oy * tail.kick_open; v2 = v2 + oz * tail.kick_open;
+      tail.x[i] = tail.x[i] + v0 * tail.drift;
+      tail.y[i] = tail.y[i] + v1 * tail.drift;
+      tail.z[i] = tail.z[i] + v2 * tail.drift;
+    }
+    tail.vx[i] = v0; tail.vy[i] = v1; tail.vz[i] = v2;
+  }
 }
 
 long long env_ll(const char* name, long long dflt) {
@@ -517,11 +576,17 @@ int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const flo
         fclose(f);
       }
     }
-    accel_sym_boundary_f32_kernel<KS, U, TJ, POT><<<nblk, BLOCK, 0, c->stream>>>(slab, bslab, nsets, H, o_begin, tps, Gs, nsets, n_pad, 0, 0);
-    NB_HIP(c, hipGetLastError());
+    // the tiles a block boundary cut are finished inside the reduce kernel; the last pass also applies the integrator tail, if one is armed
+    const SymCut cut{nslots > 0 ? bslab : nullptr, nsets, o_begin, s_begin, tps, TJ, HS};
+    SymTail tail{};
+    if (c->tail.armed && ps == npass - 1) {
+      tail = SymTail{(float*)c->tail.vx, (float*)c->tail.vy, (float*)c->tail.vz, (float*)c->tail.x, (float*)c->tail.y, (float*)c->tail.z,
+                     (float)c->tail.kick_close, (float)c->tail.kick_open, (float)c->tail.drift, c->tail.advance ? 1 : 0};
+      c->tail.done = true;
+    }
     accel_sym_reduce_f32_kernel<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(part, Gs, nblk, (long long)tps * HS, SET, 0, slab, nslots, (int)n, n_pad, G,
                                                                                  uniform ? m : nullptr, tot, ps == 0, ps == npass - 1,
-                                                                                 ax, ay, az, accumulate, phi, 0);
+                                                                                 ax, ay, az, accumulate, phi, 0, cut, tail);
     NB_HIP(c, hipGetLastError());
   }
   return NB_OK;
@@ -576,11 +641,11 @@ int run_cross(nb_ctx* c, const float* xa, const float* ya, const float* za, cons
     const int i_begin = b0 * SET, i_end = (int)std::min<int64_t>(na, (int64_t)(b0 + nb_sets) * SET);
     accel_sym_reduce_f32_kernel<<<(i_end - i_begin + 255) / 256, 256, 0, c->stream>>>(part, Gs, nb_launch, (long long)tps * HS, SET, b0, nullptr, 0, i_end, npa, G,
                                                                                        uniform ? ma : nullptr, nullptr, 1, 1, aax, aay, aaz,
-                                                                                       flags & NB_ACCUMULATE, phi_a, i_begin);
+                                                                                       flags & NB_ACCUMULATE, phi_a, i_begin, SymCut{}, SymTail{});
     NB_HIP(c, hipGetLastError());
     // B's sums: this pass' slots, added to what earlier passes left
     accel_sym_reduce_f32_kernel<<<(int)((nb + 255) / 256), 256, 0, c->stream>>>(nullptr, 0, 0, 0, SET, 0, slab, nb_sets, (int)nb, npb, G, uniform ? ma : nullptr,
-                                                                                 nullptr, 1, 1, bax, bay, baz, b0 > 0, phi_b, 0);
+                                                                                 nullptr, 1, 1, bax, bay, baz, b0 > 0, phi_b, 0, SymCut{}, SymTail{});
     NB_HIP(c, hipGetLastError());
   }
   return NB_OK;

@@ -247,19 +247,26 @@ accel_sym_boundary_f64_kernel(double* __restrict__ slab, const double* __restric
     for (int e = threadIdx.x; e < TJ; e += BLOCK) sl[(size_t)cc * n_pad_src + e] += bs[cc * TJ + e];
 }
 
+// cut tiles finished by the reduce kernel and the integrator tail it may apply: see accel_sym_f32.hip
+struct SymCut { const double* bslab; int nsets, o_begin, s_begin, tps, tj, hs; };
+struct SymTail { double *vx, *vy, *vz, *x, *y, *z; double kick_close, kick_open, drift; int advance; };
+
 // a[c][i] (+)= g * ( sum_seg part[seg][c][i] + sum_s slab[s][c][i] ), fixed order; several passes collect in `tot` first. The part slots of
-// a particle are those of the blocks that shared its sink set (nblk = 0: no part slab) — see accel_sym_f32.hip
+// a particle are those of the blocks that shared its sink set (nblk = 0: no part slab); cut.bslab non-null: the share of a block that started
+// inside the particle's tile is added to the slab entry here; tail.vx non-null: the leapfrog tail (nb_ctx::Tail) — see accel_sym_f32.hip
 __global__ void __launch_bounds__(256)
 accel_sym_reduce_f64_kernel(const double* __restrict__ part, long long Gs, int nblk, long long S, int set_size, int b0,
                             const double* __restrict__ slab, int nslots, int n, size_t n_pad,
                             double G, const double* __restrict__ m0, double* __restrict__ tot, int first, int last,
                             double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az, int accumulate, double* __restrict__ phi,
-                            int i_begin) {
+                            int i_begin, SymCut cut, SymTail tail) {
+  __shared__ int cut_block[256];
   const int nc = phi ? 4 : 3;
-  const int i = i_begin + blockIdx.x * blockDim.x + threadIdx.x;      // particles [i_begin, n)
-  if (i >= n) return;
+  const int i0 = i_begin + blockIdx.x * blockDim.x;                    // particles [i_begin, n)
+  const int i = i0 + threadIdx.x;
+  const bool live = i < n;
   double sx = 0.0, sy = 0.0, sz = 0.0, sp = 0.0;
-  if (nblk > 0) {
+  if (live && nblk > 0) {
     const long long bb = i / set_size - b0;
     const int nseg = part_block_of((bb + 1) * S - 1, Gs, nblk) - part_block_of(bb * S, Gs, nblk) + 1;
     for (int g = 0; g < nseg; ++g) {
@@ -268,12 +275,46 @@ accel_sym_reduce_f64_kernel(const double* __restrict__ part, long long Gs, int n
       if (phi) sp += p[3 * n_pad + i];
     }
   }
+  if (!cut.bslab) {
+    if (live) {
 #pragma unroll 8
-  for (int s = 0; s < nslots; ++s) {
-    const double* p = slab + (size_t)s * nc * n_pad;
-    sx += p[i]; sy += p[n_pad + i]; sz += p[2 * n_pad + i];
-    if (phi) sp += p[3 * n_pad + i];
+      for (int s = 0; s < nslots; ++s) {
+        const double* p = slab + (size_t)s * nc * n_pad;
+        sx += p[i]; sy += p[n_pad + i]; sz += p[2 * n_pad + i];
+        if (phi) sp += p[3 * n_pad + i];
+      }
+    }
+  } else {
+    const int c = i0 / set_size, r0 = i0 - c * set_size, q = r0 / cut.tj, e = r0 - q * cut.tj + (int)threadIdx.x;
+    for (int s0 = 0; s0 < nslots; s0 += 256) {
+      const int ns = nslots - s0 < 256 ? nslots - s0 : 256;
+      if (s0 > 0) __syncthreads();
+      if ((int)threadIdx.x < ns) {
+        const int o = cut.s_begin + s0 + (int)threadIdx.x;
+        int bb = c - o; if (bb < 0) bb += cut.nsets;
+        const long long g0 = ((long long)bb * cut.tps + (long long)(o - cut.o_begin) * (set_size / cut.tj) + q) * cut.hs;
+        const int k0 = part_block_of(g0, Gs, nblk);
+        cut_block[threadIdx.x] = part_begin(k0 + 1, Gs, nblk) < g0 + cut.hs ? k0 + 1 : -1;
+      }
+      __syncthreads();
+      if (live) {
+#pragma unroll 4
+        for (int s = 0; s < ns; ++s) {
+          const double* p = slab + (size_t)(s0 + s) * nc * n_pad;
+          double vx = p[i], vy = p[n_pad + i], vz = p[2 * n_pad + i], vp = phi ? p[3 * n_pad + i] : 0.0;
+          const int kb = cut_block[s];
+          if (kb >= 0) {
+            const double* bs = cut.bslab + (size_t)kb * nc * cut.tj + e;
+            vx += bs[0]; vy += bs[cut.tj]; vz += bs[2 * cut.tj];
+            if (phi) vp += bs[3 * cut.tj];
+          }
+          sx += vx; sy += vy; sz += vz;
+          if (phi) sp += vp;
+        }
+      }
+    }
   }
+  if (!live) return;
   if (tot) {
     if (!first) { sx += tot[i]; sy += tot[(size_t)n + i]; sz += tot[2 * (size_t)n + i]; if (phi) sp += tot[3 * (size_t)n + i]; }
     if (!last) { tot[i] = sx; tot[(size_t)n + i] = sy; tot[2 * (size_t)n + i] = sz; if (phi) tot[3 * (size_t)n + i] = sp; return; }
@@ -283,6 +324,19 @@ accel_sym_reduce_f64_kernel(const double* __restrict__ part, long long Gs, int n
   double ox = g * sx, oy = g * sy, oz = g * sz;
   if (accumulate) { ox += ax[i]; oy += ay[i]; oz += az[i]; }
   ax[i] = ox; ay[i] = oy; az[i] = oz;
+  if (tail.vx) {                                            // as kick_kernel / kick_drift_kernel (integrate.hip): products and sums rounded one by one
+#pragma clang fp contract(off)
+    double v0 = tail.vx[i] + ox * tail.kick_close;
+    double v1 = tail.vy[i] + oy * tail.kick_close;
+    double v2 = tail.vz[i] + oz * tail.kick_close;
+    if (tail.advance) {
+      v0 = v0 + ox * tail.kick_open; v1 = v1 + oy * tail.kick_open; v2 = v2 + oz * tail.kick_open;
+      tail.x[i] = tail.x[i] + v0 * tail.drift;
+      tail.y[i] = tail.y[i] + v1 * tail.drift;
+      tail.z[i] = tail.z[i] + v2 * tail.drift;
+    }
+    tail.vx[i] = v0; tail.vy[i] = v1; tail.vz[i] = v2;
+  }
 }
 
 long long env_ll(const char* name, long long dflt) {
@@ -373,11 +427,17 @@ int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const 
     kernel<<<nblk, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, nsets, H, o_begin, tps, Gs, eps2, part, slab, bslab, n_pad,
                                           x, y, z, m, (int)n, nsets, n_pad, 0, 0, turn_shift);
     NB_HIP(c, hipGetLastError());
-    accel_sym_boundary_f64_kernel<KS, TJ, POT><<<nblk, BLOCK, 0, c->stream>>>(slab, bslab, nsets, H, o_begin, tps, Gs, nsets, n_pad, 0, 0);
-    NB_HIP(c, hipGetLastError());
+    // the tiles a block boundary cut are finished inside the reduce kernel; the last pass also applies the integrator tail, if one is armed
+    const SymCut cut{nslots > 0 ? bslab : nullptr, nsets, o_begin, s_begin, tps, TJ, HS};
+    SymTail tail{};
+    if (c->tail.armed && ps == npass - 1) {
+      tail = SymTail{(double*)c->tail.vx, (double*)c->tail.vy, (double*)c->tail.vz, (double*)c->tail.x, (double*)c->tail.y, (double*)c->tail.z,
+                     c->tail.kick_close, c->tail.kick_open, c->tail.drift, c->tail.advance ? 1 : 0};
+      c->tail.done = true;
+    }
     accel_sym_reduce_f64_kernel<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(part, Gs, nblk, (long long)tps * HS, SET, 0, slab, nslots, (int)n, n_pad, G,
                                                                                  uniform ? m : nullptr, tot, ps == 0, ps == npass - 1,
-                                                                                 ax, ay, az, accumulate, phi, 0);
+                                                                                 ax, ay, az, accumulate, phi, 0, cut, tail);
     NB_HIP(c, hipGetLastError());
   }
   return NB_OK;
@@ -430,10 +490,10 @@ int run_cross(nb_ctx* c, const double* xa, const double* ya, const double* za, c
     const int i_begin = b0 * SET, i_end = (int)std::min<int64_t>(na, (int64_t)(b0 + nb_sets) * SET);
     accel_sym_reduce_f64_kernel<<<(i_end - i_begin + 255) / 256, 256, 0, c->stream>>>(part, Gs, nb_launch, (long long)tps * HS, SET, b0, nullptr, 0, i_end, npa, G,
                                                                                        uniform ? ma : nullptr, nullptr, 1, 1, aax, aay, aaz,
-                                                                                       flags & NB_ACCUMULATE, phi_a, i_begin);
+                                                                                       flags & NB_ACCUMULATE, phi_a, i_begin, SymCut{}, SymTail{});
     NB_HIP(c, hipGetLastError());
     accel_sym_reduce_f64_kernel<<<(int)((nb + 255) / 256), 256, 0, c->stream>>>(nullptr, 0, 0, 0, SET, 0, slab, nb_sets, (int)nb, npb, G, uniform ? ma : nullptr,
-                                                                                 nullptr, 1, 1, bax, bay, baz, b0 > 0, phi_b, 0);
+                                                                                 nullptr, 1, 1, bax, bay, baz, b0 > 0, phi_b, 0, SymCut{}, SymTail{});
     NB_HIP(c, hipGetLastError());
   }
   return NB_OK;

@@ -333,6 +333,36 @@ static int refresh_acc(nb_ctx* c, double eps, double G, double* phi = nullptr) {
   return NB_OK;
 }
 
+// a(x) of the context's state followed by the leapfrog tail  v += a * close  [; v += a * open ; x += v * drift  when `advance`]. The force
+// path applies the tail in the kernel that completes the accelerations where it can (pair-symmetric kernels: nb_ctx::Tail); otherwise the
+// plain kick / kick-drift kernels run behind it — the same arithmetic either way. After an advancing tail the cached accelerations belong
+// to the previous positions.
+static int accel_with_tail(nb_ctx* c, double eps, double G, double close, bool advance, double open, double drift, double* phi = nullptr) {
+  const size_t b = (size_t)c->n * esize(c->dtype);
+  char* s = reinterpret_cast<char*>(c->state);
+  void *x = s, *y = s + b, *z = s + 2 * b, *vx = s + 4 * b, *vy = s + 5 * b, *vz = s + 6 * b;
+  void *ax = s + 7 * b, *ay = s + 8 * b, *az = s + 9 * b;
+  c->tail = nb_ctx::Tail{};
+  if (c->solver == NB_SOLVER_DIRECT) {
+    c->tail.vx = vx; c->tail.vy = vy; c->tail.vz = vz; c->tail.x = x; c->tail.y = y; c->tail.z = z;
+    c->tail.kick_close = close; c->tail.kick_open = open; c->tail.drift = drift; c->tail.advance = advance; c->tail.armed = true;
+  }
+  int rc = refresh_acc(c, eps, G, phi);
+  const bool done = c->tail.done;
+  c->tail = nb_ctx::Tail{};
+  if (rc) return rc;
+  if (!done) {
+    if (advance) rc = nb_launch_kick_drift(c, c->dtype, x, y, z, vx, vy, vz, ax, ay, az, c->n, close, open, drift);
+    else rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, close);
+    if (rc) return rc;
+  }
+  if (advance) {
+    c->acc_valid = false;
+    if (c->solver >= NB_SOLVER_EWALD) { rc = nb_launch_wrap(c, c->dtype, x, y, z, c->n, c->box); if (rc) return rc; }
+  }
+  return NB_OK;
+}
+
 int nb_accel(nb_ctx* c, double eps, double G, void* ax, void* ay, void* az) {
   if (!c) return NB_ERR_ARG;
   if (!c->has_state) return nb_fail(c, NB_ERR_STATE, "nb_accel: call nb_set_state first");
@@ -388,20 +418,25 @@ int nb_step(nb_ctx* c, double dt, int64_t nsteps, double eps, double G) {
   void *x = s, *y = s + b, *z = s + 2 * b, *vx = s + 4 * b, *vy = s + 5 * b, *vz = s + 6 * b;
   void *ax = s + 7 * b, *ay = s + 8 * b, *az = s + 9 * b;
   const double h = 0.5 * dt;
-  // Launch-bound regime (small N, many steps): steps 1..n-1 are identical launch sequences
-  // [kick_drift(h, h, dt); a(x)] with constant arguments, so capture one into a hipGraph and replay it.
+  // Step k: opening half kick + drift (a launch of its own for step 0 only), force at the new positions, and the TAIL — the closing half
+  // kick of step k and, unless it is the last, the opening half kick and drift of step k + 1 — applied by the kernel that completes the
+  // accelerations (accel_with_tail): two launches per step with the pair-symmetric kernels instead of five.
+  // Launch-bound regime (small N, many steps): steps 1..n-2 are identical launch sequences with constant arguments, so capture one into a
+  // hipGraph and replay it.
   static const bool no_graph = getenv("NB_NO_GRAPH") != nullptr;
   // (never on HIP's legacy NULL stream: it cannot be captured)
   const bool use_graph = !no_graph && c->stream != nullptr && c->solver == NB_SOLVER_DIRECT && c->n <= 65536 && nsteps >= 4;
+  rc = nb_launch_kick_drift(c, c->dtype, x, y, z, vx, vy, vz, ax, ay, az, c->n, 0.0, h, dt); if (rc) return rc;
+  if (c->solver >= NB_SOLVER_EWALD) { rc = nb_launch_wrap(c, c->dtype, x, y, z, c->n, c->box); if (rc) return rc; }
   for (int64_t k = 0; k < nsteps; ++k) {
-    if (use_graph && k >= 1) {
+    const bool last = k == nsteps - 1;
+    if (use_graph && k >= 1 && !last) {
       if (!c->step_graph || c->graph_dt != dt || c->graph_eps != eps || c->graph_G != G) {
         if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
         // step 0 ran eagerly above, so the scratch buffer already has its final size: no allocation in capture
         hipGraph_t g = nullptr;
         NB_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        rc = nb_launch_kick_drift(c, c->dtype, x, y, z, vx, vy, vz, ax, ay, az, c->n, h, h, dt);
-        if (!rc) rc = refresh_acc(c, eps, G);
+        rc = accel_with_tail(c, eps, G, h, true, h, dt);
         hipError_t e = hipStreamEndCapture(c->stream, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) return nb_fail(c, NB_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -413,13 +448,9 @@ int nb_step(nb_ctx* c, double dt, int64_t nsteps, double eps, double G) {
       NB_HIP(c, hipGraphLaunch(c->step_graph, c->stream));
       continue;
     }
-    // step k: [closing half-kick of step k-1, fused] opening half-kick, drift; force; (closing kick deferred)
-    rc = nb_launch_kick_drift(c, c->dtype, x, y, z, vx, vy, vz, ax, ay, az, c->n, k == 0 ? 0.0 : h, h, dt);
-    if (rc) return rc;
-    if (c->solver >= NB_SOLVER_EWALD) { rc = nb_launch_wrap(c, c->dtype, x, y, z, c->n, c->box); if (rc) return rc; }
-    rc = refresh_acc(c, eps, G); if (rc) return rc;
+    rc = accel_with_tail(c, eps, G, h, !last, h, dt); if (rc) return rc;
   }
-  rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, h); if (rc) return rc;
+  c->acc_valid = true; c->acc_eps = eps; c->acc_G = G;      // the last force belongs to the final positions (graph replays included)
   NB_HIP(c, hipStreamSynchronize(c->stream));
   return nb_bh_check(c);
 }
@@ -429,11 +460,9 @@ static int kdk_enqueue(nb_ctx* c, double kick1, double drift, double kick2, doub
   char* s = reinterpret_cast<char*>(c->state);
   void *x = s, *y = s + b, *z = s + 2 * b, *vx = s + 4 * b, *vy = s + 5 * b, *vz = s + 6 * b;
   void *ax = s + 7 * b, *ay = s + 8 * b, *az = s + 9 * b;
-  int rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, kick1); if (rc) return rc;
-  rc = nb_launch_drift(c, c->dtype, x, y, z, vx, vy, vz, c->n, drift); if (rc) return rc;
+  int rc = nb_launch_kick_drift(c, c->dtype, x, y, z, vx, vy, vz, ax, ay, az, c->n, 0.0, kick1, drift); if (rc) return rc;   // v += a*kick1; x += v*drift
   if (c->solver >= NB_SOLVER_EWALD) { rc = nb_launch_wrap(c, c->dtype, x, y, z, c->n, c->box); if (rc) return rc; }
-  rc = refresh_acc(c, eps, G); if (rc) return rc;
-  return nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, kick2);
+  return accel_with_tail(c, eps, G, kick2, false, 0.0, 0.0);
 }
 
 int nb_kdk_step(nb_ctx* c, double kick1, double drift, double kick2, double eps, double G) {
@@ -689,8 +718,7 @@ int nb_step_energy(nb_ctx* c, double dt, int64_t nsteps, double eps, double G, d
   const double h = 0.5 * dt;
   for (int64_t k = 0; k < nsteps; ++k) {
     rc = nb_launch_kick_drift(c, c->dtype, x, y, z, vx, vy, vz, ax, ay, az, c->n, 0.0, h, dt); if (rc) return rc;
-    rc = refresh_acc(c, eps, G, c->phi); if (rc) return rc;
-    rc = nb_launch_kick(c, c->dtype, vx, vy, vz, ax, ay, az, c->n, h); if (rc) return rc;   // synchronised velocities
+    rc = accel_with_tail(c, eps, G, h, false, 0.0, 0.0, c->phi); if (rc) return rc;        // closing half kick with the force: synchronised velocities
     rc = nb_launch_kinetic(c, c->dtype, vx, vy, vz, m, c->n, c->elog + 2 * k); if (rc) return rc;
     rc = nb_launch_pot_energy(c, c->dtype, c->phi, m, c->n, eps * eps, c->dtype == NB_F32 && c->uniform_mass,
                               c->elog + 2 * k + 1); if (rc) return rc;
@@ -821,6 +849,36 @@ int nb_kick_dev(nb_ctx* c, int dtype, void* vx, void* vy, void* vz, const void* 
   if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_kick_dev: unknown dtype");
   int rc = use_device(c); if (rc) return rc;
   return nb_launch_kick(c, dtype, vx, vy, vz, ax, ay, az, n, h);
+}
+
+int nb_kick_drift_dev(nb_ctx* c, int dtype, void* x, void* y, void* z, void* vx, void* vy, void* vz,
+                      const void* ax, const void* ay, const void* az, int64_t n, double kick, double drift) {
+  if (!c) return NB_ERR_ARG;
+  NB_SINGLE_ONLY(c, "nb_kick_drift_dev");
+  if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_kick_drift_dev: unknown dtype");
+  if (n < 0 || (n > 0 && (!x || !y || !z || !vx || !vy || !vz || !ax || !ay || !az))) return nb_fail(c, NB_ERR_ARG, "nb_kick_drift_dev: bad argument");
+  int rc = use_device(c); if (rc) return rc;
+  return nb_launch_kick_drift(c, dtype, x, y, z, vx, vy, vz, ax, ay, az, n, 0.0, kick, drift);
+}
+
+int nb_accel_kdk_dev(nb_ctx* c, int dtype, void* xi, void* yi, void* zi, int64_t n_snk,
+                     const void* xs, const void* ys, const void* zs, const void* ms, int64_t n_src,
+                     double eps, double G, void* ax, void* ay, void* az, int flags,
+                     void* vx, void* vy, void* vz, double kick_close, double kick_open, double drift) {
+  if (!c) return NB_ERR_ARG;
+  NB_SINGLE_ONLY(c, "nb_accel_kdk_dev");
+  if (dtype != NB_F32 && dtype != NB_F64) return nb_fail(c, NB_ERR_ARG, "nb_accel_kdk_dev: unknown dtype");
+  if (n_snk > 0 && (!vx || !vy || !vz)) return nb_fail(c, NB_ERR_ARG, "nb_accel_kdk_dev: NULL velocity array");
+  const bool advance = kick_open != 0.0 || drift != 0.0;
+  c->tail = nb_ctx::Tail{};
+  c->tail.vx = vx; c->tail.vy = vy; c->tail.vz = vz; c->tail.x = xi; c->tail.y = yi; c->tail.z = zi;
+  c->tail.kick_close = kick_close; c->tail.kick_open = kick_open; c->tail.drift = drift; c->tail.advance = advance; c->tail.armed = true;
+  int rc = nb_accel_dev(c, dtype, xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, eps, G, ax, ay, az, flags);
+  const bool done = c->tail.done;
+  c->tail = nb_ctx::Tail{};
+  if (rc || done) return rc;
+  if (advance) return nb_launch_kick_drift(c, dtype, xi, yi, zi, vx, vy, vz, ax, ay, az, n_snk, kick_close, kick_open, drift);
+  return nb_launch_kick(c, dtype, vx, vy, vz, ax, ay, az, n_snk, kick_close);
 }
 
 int nb_drift_dev(nb_ctx* c, int dtype, void* x, void* y, void* z, const void* vx, const void* vy, const void* vz,

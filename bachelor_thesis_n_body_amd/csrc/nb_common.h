@@ -46,6 +46,16 @@ struct nb_ctx {
   long long sym_enable = -1, sym_min_n = -1, sym_slab_bytes = -1;
   long long sym_scratch_limit = -1;   // NB_OPT_SYM_SCRATCH_LIMIT: the most scratch the pair-symmetric kernels may ask the allocator for (-1: no limit)
   bool last_accel_sym = false;
+  // Integrator tail handed to the NEXT force launch (nb_accel_kdk_dev, nb_step): the kernel that writes the accelerations of a particle also
+  // applies  v += a * kick_close;  and, when `advance`,  v += a * kick_open;  x += v * drift  (the closing half kick of the step the force
+  // belongs to, the opening half kick and drift of the next) — one launch instead of up to three at launch-sensitive sizes. A force path
+  // that can do it sets `done`; the caller runs the plain kick / kick-drift kernels otherwise. Products and sums rounded separately, as in
+  // integrate.hip.
+  struct Tail {
+    void *vx = nullptr, *vy = nullptr, *vz = nullptr, *x = nullptr, *y = nullptr, *z = nullptr;
+    double kick_close = 0.0, kick_open = 0.0, drift = 0.0;
+    bool armed = false, advance = false, done = false;
+  } tail;
   bool graph_replayed = false;   // the last nb_kdk_run replayed a captured step (diagnostic: nb_last_run_used_graph)
   // force solver used by nb_accel / nb_step: direct summation (default) or Barnes-Hut tree (fp32 only)
   int solver = 0;

@@ -112,6 +112,26 @@ class HipKernels:
                                     ax, ay, az, (_lib.NB_ACCUMULATE if accumulate else 0) | (_lib.NB_UNIFORM_MASS if uniform_mass else 0))
         _lib.check(self._ctx, rc, "nb_accel_dev")
 
+    def accel_kdk(self, snk, n_snk, src, n_src, eps, G, acc, accumulate, vel, kick_close, kick_open=0.0, drift=0.0, uniform_mass=False):
+        """accel() followed by the leapfrog tail on the sinks (nb_accel_kdk_dev): vel += acc*kick_close and, when kick_open or drift is
+        non-zero, vel += acc*kick_open; snk[:3] += vel*drift — applied inside the force's last kernel where the pair-symmetric kernels run."""
+        self._bind()
+        xi, yi, zi = self._rows(snk, 3)
+        xs, ys, zs, ms = self._rows(src, 4)
+        ax, ay, az = self._rows(acc, 3)
+        vx, vy, vz = self._rows(vel, 3)
+        rc = self._lib.nb_accel_kdk_dev(self._ctx, self._code(snk), xi, yi, zi, n_snk, xs, ys, zs, ms, n_src, eps, G, ax, ay, az,
+                                        (_lib.NB_ACCUMULATE if accumulate else 0) | (_lib.NB_UNIFORM_MASS if uniform_mass else 0),
+                                        vx, vy, vz, kick_close, kick_open, drift)
+        _lib.check(self._ctx, rc, "nb_accel_kdk_dev")
+
+    def kick_drift(self, pm, vel, acc, n, kick, drift):
+        self._bind()
+        x, y, z = self._rows(pm, 3)
+        vx, vy, vz = self._rows(vel, 3)
+        ax, ay, az = self._rows(acc, 3)
+        _lib.check(self._ctx, self._lib.nb_kick_drift_dev(self._ctx, self._code(vel), x, y, z, vx, vy, vz, ax, ay, az, n, kick, drift), "nb_kick_drift_dev")
+
     def accel_pot(self, snk, n_snk, src, n_src, eps, G, acc, phi, accumulate, uniform_mass=False):
         """accel() that also fills phi (float64[n_snk]): sum_j m_j / sqrt(r^2 + eps^2), self term included, no G."""
         self._bind()
@@ -596,9 +616,15 @@ class ShardedEngine:
         else:
             closing()
 
-    def accel(self, eps: float, G: float = 1.0, with_potential: bool = False) -> None:
-        """acc <- a(x) of the owned sinks due to ALL particles; with_potential also accumulates self.phi over the chunks."""
+    def _tail_fused(self) -> bool:
+        """One rank owning every particle: the force launch can apply the leapfrog tail itself (HipKernels.accel_kdk)."""
+        return self.world == 1 and not self.pairwise and hasattr(self.k, "accel_kdk")
+
+    def accel(self, eps: float, G: float = 1.0, with_potential: bool = False, tail=None) -> None:
+        """acc <- a(x) of the owned sinks due to ALL particles; with_potential also accumulates self.phi over the chunks. `tail` =
+        (kick_close, kick_open, drift), one rank only: the leapfrog tail applied with the force (step())."""
         tm = self.kernel_timer
+        assert tail is None or (self._tail_fused() and not with_potential)
         if with_potential and self.phi is None:
             self.phi = self._torch.zeros(self.n_max, dtype=self._torch.float64, device=self.device)
         if self.pairwise:
@@ -611,6 +637,8 @@ class ShardedEngine:
                 tm.begin()
             if with_potential:
                 self.k.accel_pot(self.pm, self.n_loc, src, self.counts[owner], eps, G, self.acc, self.phi, not first, self.uniform_mass)
+            elif tail is not None:
+                self.k.accel_kdk(self.pm, self.n_loc, src, self.counts[owner], eps, G, self.acc, not first, self.vel, *tail, uniform_mass=self.uniform_mass)
             else:
                 self.k.accel(self.pm, self.n_loc, src, self.counts[owner], eps, G, self.acc, not first, self.uniform_mass)
             if tm is not None:
@@ -626,9 +654,20 @@ class ShardedEngine:
         if self._acc_key != (eps, G):
             self.accel(eps, G)
         h = 0.5 * dt
+        if self._tail_fused():
+            # one rank: the kernel that completes the accelerations also applies the closing half kick and, between the steps of one call,
+            # the next opening half kick and drift — two launches per step after the first (include/nbody_amd.h: nb_accel_kdk_dev)
+            self.k.kick_drift(self.pm, self.vel, self.acc, self.n_loc, h, dt)
+            for s in range(int(nsteps)):
+                self.accel(eps, G, tail=(h, 0.0, 0.0) if s == nsteps - 1 else (h, h, dt))
+            return
+        kd = getattr(self.k, "kick_drift", None)
         for _ in range(int(nsteps)):
-            self.k.kick(self.vel, self.acc, self.n_loc, h)
-            self.k.drift(self.pm, self.vel, self.n_loc, dt)
+            if kd is not None:
+                kd(self.pm, self.vel, self.acc, self.n_loc, h, dt)
+            else:
+                self.k.kick(self.vel, self.acc, self.n_loc, h)
+                self.k.drift(self.pm, self.vel, self.n_loc, dt)
             self.accel(eps, G)
             self.k.kick(self.vel, self.acc, self.n_loc, h)
 

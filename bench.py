@@ -566,11 +566,17 @@ def main():
         if probe is not None:
             probe.enabled = True
         t0 = time.perf_counter()
-        for k in range(args.steps):
-            if inject is not None and inject == (rank, idx, k):
-                time.sleep(1e6)
-            eng.step(dt, 1, eps, G)
-            hb(f"{name}: step {k + 1} of {args.steps} enqueued")
+        if world == 1 and inject is None:
+            # one rank: the K steps as ONE call, as a run would make it — between the steps of a call the kernel that completes the accelerations
+            # also applies the closing half kick and the next opening half kick and drift (two launches per step; nb_accel_kdk_dev)
+            eng.step(dt, args.steps, eps, G)
+            hb(f"{name}: {args.steps} steps enqueued")
+        else:
+            for k in range(args.steps):
+                if inject is not None and inject == (rank, idx, k):
+                    time.sleep(1e6)
+                eng.step(dt, 1, eps, G)
+                hb(f"{name}: step {k + 1} of {args.steps} enqueued")
         if clock is not None:
             clock.stop(torch.cuda.current_stream().cuda_stream)
         sync()

@@ -240,6 +240,20 @@ int nb_kick_dev(nb_ctx* ctx, int dtype, void* vx, void* vy, void* vz,
                 const void* ax, const void* ay, const void* az, int64_t n, double h);
 int nb_drift_dev(nb_ctx* ctx, int dtype, void* x, void* y, void* z,
                  const void* vx, const void* vy, const void* vz, int64_t n, double dt);
+/* Both in one pass over the state: v += a*kick ; x += v*drift (the opening half of a KDK step; same arithmetic as nb_kick_dev + nb_drift_dev). */
+int nb_kick_drift_dev(nb_ctx* ctx, int dtype, void* x, void* y, void* z, void* vx, void* vy, void* vz,
+                      const void* ax, const void* ay, const void* az, int64_t n, double kick, double drift);
+/* nb_accel_dev followed by the leapfrog TAIL on the sinks:  v += a*kick_close  (the closing half kick of the step the force belongs to) and,
+ * when kick_open or drift is non-zero,  v += a*kick_open ; xi += v*drift  (the opening half kick and drift of the NEXT step — the sink
+ * positions move; where sinks and sources are the same arrays so do the sources). Bit-identical to nb_accel_dev + nb_kick_dev
+ * [+ nb_kick_drift_dev]; where the force runs on the pair-symmetric kernels the tail is applied by the kernel that completes the
+ * accelerations, so a whole step is two launches (force, reduce + tail) instead of five — at N = 32 768 ... 131 072 the small launches and the
+ * gaps between them were 15 ... 1.5 % of a step (profiles/r04_step_timeline_small_n.txt). The reference's integrator is the same KDK
+ * sequence as separate NumPy statements. */
+int nb_accel_kdk_dev(nb_ctx* ctx, int dtype, void* xi, void* yi, void* zi, int64_t n_snk,
+                     const void* xs, const void* ys, const void* zs, const void* ms, int64_t n_src,
+                     double eps, double G, void* ax, void* ay, void* az, int flags,
+                     void* vx, void* vy, void* vz, double kick_close, double kick_open, double drift);
 
 #ifdef __cplusplus
 }
