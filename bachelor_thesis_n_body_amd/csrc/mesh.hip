@@ -54,6 +54,8 @@ struct nb_mesh_state {
   int *cell_start = nullptr, *chunk_cnt = nullptr, *chunk_off = nullptr;
   int4* chunk_info = nullptr;        // tile kernel: (row, first, last) per chunk
   int64_t chunk_info_cap = 0;
+  double* stage = nullptr;           // brick deposit: one 2 x 10^3 tile per chunk, summed into the grid by brick_assemble_kernel
+  int64_t stage_cap = 0;             // in chunks
   void* tmp = nullptr;
   size_t tmp_bytes = 0;
   float* table = nullptr;            // long-range complement of the pair force tabulated in r^2 (fp32 short-range kernel)
@@ -68,9 +70,18 @@ constexpr int SUBBITS = 6; // sub-cell bits below the cell index in the sort key
 
 struct d4 { double x, y, z, w; };
 
+// periodic wrap of a cell index. A 64-bit remainder by a run-time divisor is ~100 instructions on this hardware and the particle kernels
+// need six to nine of them per particle: particles inside the box (the usual case) take none
 __device__ inline int wrap_index(long long i, int n) {
+  if ((unsigned long long)i < (unsigned long long)n) return (int)i;
   int r = (int)(i % n);
   return r < 0 ? r + n : r;
+}
+// the same for an index known to lie in [-n, 2n) (tile cells around a brick)
+__device__ inline int wrap_near(int i, int n) {
+  if (i < 0) return i + n;
+  if (i >= n) { i -= n; if (i >= n) i %= n; }          // (a mesh smaller than a brick tile wraps more than once)
+  return i;
 }
 
 // CIC deposit of particle masses onto one lattice; `shift` = 0 (lattice 1, real part) or 0.5 (lattice displaced by half
@@ -114,7 +125,13 @@ mesh_kspace_kernel(const hipfftDoubleComplex* __restrict__ in, hipfftDoubleCompl
   const size_t cells = (size_t)N * N * N;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= cells) return;
-  const int iz = (int)(idx % N), iy = (int)((idx / N) % N), ix = (int)(idx / ((size_t)N * N));
+  int ix, iy, iz;
+  if (cells <= 0xffffffffull) {           // two 32-bit divisions instead of three 64-bit ones (~100 instructions each on this hardware)
+    const unsigned id = (unsigned)idx, row = id / (unsigned)N;
+    iz = (int)(id - row * (unsigned)N); ix = (int)(row / (unsigned)N); iy = (int)(row - (unsigned)ix * (unsigned)N);
+  } else {
+    iz = (int)(idx % N); iy = (int)((idx / N) % N); ix = (int)(idx / ((size_t)N * N));
+  }
   const int half = N / 2;
   const bool nyq = (N % 2 == 0) && (ix == half || iy == half || iz == half);
   hipfftDoubleComplex z0 = {0.0, 0.0};
@@ -210,51 +227,85 @@ brick_key_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __re
   idx[p] = (uint32_t)p;
 }
 
-// block -> (brick, first particle, one-past-last particle); false when the block is beyond the last chunk
-__device__ inline bool brick_of_block(const int* __restrict__ brick_start, const int* __restrict__ chunk_off, int nb3, int& brick, int& p0, int& p1) {
-  const int w = blockIdx.x;
-  if (w >= chunk_off[nb3]) return false;
-  int lo = 0, hi = nb3;
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_off[mid] <= w) lo = mid; else hi = mid; }
-  brick = lo;
-  p0 = brick_start[brick] + (w - chunk_off[brick]) * BCH;
-  p1 = min(brick_start[brick + 1], p0 + BCH);
-  return true;
+// block -> (brick, first particle, one-past-last particle) from the chunk table brick_prepare builds (chunk_info_kernel: one binary search per
+// chunk in a streaming kernel — 15 dependent loads at the start of every short-lived block cost the gather 0.2 ms of 0.75 at 256^3); false
+// when the block is beyond the last chunk
+__device__ inline bool brick_of_block(const int4* __restrict__ chunk_info, int w, int& brick, int& p0, int& p1) {
+  const int4 ci = chunk_info[w];
+  brick = ci.x; p0 = ci.y; p1 = ci.z + 1;
+  return ci.x >= 0;
 }
-
-// CIC weights and brick-local base cell of one particle on lattice `lat` (0: as is, 1: shifted by half a cell)
+// CIC weights and brick-local base cells of one particle on both lattices (0: as is, 1: shifted by half a cell). The brick kernels are bound
+// by instruction issue, not by memory (ablation in DESIGN.md §6.7), so this is written for few instructions: the cell index through a 32-bit
+// conversion when the coordinate is inside the box (else the general 64-bit wrap), and lattice 2 from lattice 1's fraction f instead of a second
+// floor: (u - 1/2) - floor(u - 1/2) is f - 1/2 in the upper half of a cell and f + 1/2, one cell lower, in the lower half — the same bits
+// (all of these subtractions are exact in fp64).
+struct cic_axis { int l1, l2; double w1, w2; };
+__device__ inline cic_axis cic_axis_in_brick(double u, int N, int origin) {
+  const double f1 = floor(u);
+  cic_axis r;
+  const int cell = (f1 >= 0.0 && f1 < (double)N) ? (int)f1 : wrap_index((long long)f1, N);
+  r.l1 = cell - origin;
+  r.w1 = u - f1;
+  const bool upper = r.w1 >= 0.5;
+  r.w2 = upper ? r.w1 - 0.5 : r.w1 + 0.5;
+  r.l2 = upper ? r.l1 : r.l1 - 1;
+  return r;
+}
 struct cic_local { int lx, ly, lz; double wx, wy, wz; };
+struct cic_both { cic_axis x, y, z; };
 template <typename T>
-__device__ inline cic_local cic_in_brick(T px, T py, T pz, double invh, int N, int ox, int oy, int oz, int lat) {
-  const double ux = (double)px * invh, uy = (double)py * invh, uz = (double)pz * invh;
-  const double f1x = floor(ux), f1y = floor(uy), f1z = floor(uz);
+__device__ inline cic_both cic_in_brick(T px, T py, T pz, double invh, int N, int ox, int oy, int oz) {
+  cic_both r;
+  r.x = cic_axis_in_brick((double)px * invh, N, ox); r.y = cic_axis_in_brick((double)py * invh, N, oy); r.z = cic_axis_in_brick((double)pz * invh, N, oz);
+  return r;
+}
+__device__ inline cic_local cic_lattice(const cic_both& c, int lat) {
   cic_local r;
-  r.lx = wrap_index((long long)f1x, N) - ox; r.ly = wrap_index((long long)f1y, N) - oy; r.lz = wrap_index((long long)f1z, N) - oz;
-  if (lat == 0) { r.wx = ux - f1x; r.wy = uy - f1y; r.wz = uz - f1z; return r; }
-  const double vx = ux - 0.5, vy = uy - 0.5, vz = uz - 0.5;
-  const double f2x = floor(vx), f2y = floor(vy), f2z = floor(vz);
-  r.lx -= (int)(f1x - f2x); r.ly -= (int)(f1y - f2y); r.lz -= (int)(f1z - f2z);     // 0 or 1 cell lower
-  r.wx = vx - f2x; r.wy = vy - f2y; r.wz = vz - f2z;
+  if (lat == 0) { r.lx = c.x.l1; r.ly = c.y.l1; r.lz = c.z.l1; r.wx = c.x.w1; r.wy = c.y.w1; r.wz = c.z.w1; }
+  else { r.lx = c.x.l2; r.ly = c.y.l2; r.lz = c.z.l2; r.wx = c.x.w2; r.wy = c.y.w2; r.wz = c.z.w2; }
   return r;
 }
 
+constexpr int BPT = BCH / 256;      // particles per thread of a chunk
+constexpr int BHEAVY = 8;           // a brick with more chunks than this is "crowded": its chunks add their tiles to the grid with atomics, in parallel
+
+// Both brick kernels are made of short blocks (<= 1024 particles, two or three dependent trips to memory each): what they cost is latency
+// unless every load a block needs is in flight at once — so a thread first fetches the indices and then the coordinates of ALL its
+// particles, and only then touches the tile (zeroing it / filling it with 12 loads per thread in flight); measured at 256^3 on a 256^3
+// mesh: gather 0.75 -> see DESIGN.md §6.7.
 template <typename T>
 __global__ void __launch_bounds__(256)
 brick_deposit_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, const T* __restrict__ m,
-                     const uint32_t* __restrict__ idx_s, const int* __restrict__ brick_start, const int* __restrict__ chunk_off,
-                     int nb3, int nbr, double invh, int N, int interlace, double* __restrict__ grid) {
+                     const uint32_t* __restrict__ idx_s, const int4* __restrict__ chunk_info,
+                     int nbr, double invh, int N, int interlace, double* __restrict__ grid, double* __restrict__ stage,
+                     const int* __restrict__ chunk_off, int which, int ablate) {
   __shared__ double tile[2][BT3];
   int brick, p0, p1;
-  if (!brick_of_block(brick_start, chunk_off, nb3, brick, p0, p1)) return;
+  if (!brick_of_block(chunk_info, (int)blockIdx.x, brick, p0, p1)) return;
+  // which = 1: only the chunks of bricks with at most BHEAVY chunks (their tiles go to `stage`); 2: only those of crowded bricks (atomic
+  // flush onto the grid brick_assemble_kernel has written); 0: every chunk, atomic flush
+  if (which) { const bool heavy = chunk_off[brick + 1] - chunk_off[brick] > BHEAVY; if (heavy != (which == 2)) return; }
   const int ox = (brick / (nbr * nbr)) * BR, oy = ((brick / nbr) % nbr) * BR, oz = (brick % nbr) * BR;
+  uint32_t q[BPT];
+  T px[BPT], py[BPT], pz[BPT], pm[BPT];
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) { const int p = p0 + u * 256 + (int)threadIdx.x; q[u] = p < p1 ? ((ablate & 4) ? (uint32_t)p : idx_s[p]) : 0u; }
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) {
+    const bool live = p0 + u * 256 + (int)threadIdx.x < p1;
+    px[u] = live ? x[q[u]] : T(0); py[u] = live ? y[q[u]] : T(0); pz[u] = live ? z[q[u]] : T(0); pm[u] = live ? m[q[u]] : T(0);
+  }
   for (int t = threadIdx.x; t < BT3; t += 256) { tile[0][t] = 0.0; tile[1][t] = 0.0; }
   __syncthreads();
-  for (int p = p0 + (int)threadIdx.x; p < p1; p += 256) {
-    const uint32_t q = idx_s[p];
-    const T px = x[q], py = y[q], pz = z[q];
-    const double mass = (double)m[q];
+  double sink = 0.0;
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) {
+    if (p0 + u * 256 + (int)threadIdx.x >= p1) break;
+    const double mass = (double)pm[u];
+    const cic_both cb = cic_in_brick(px[u], py[u], pz[u], invh, N, ox, oy, oz);
     for (int lat = 0; lat < (interlace ? 2 : 1); ++lat) {
-      const cic_local c = cic_in_brick(px, py, pz, invh, N, ox, oy, oz, lat);
+      const cic_local c = cic_lattice(cb, lat);
       const double wx[2] = {(1.0 - c.wx) * mass, c.wx * mass}, wy[2] = {1.0 - c.wy, c.wy}, wz[2] = {1.0 - c.wz, c.wz};
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -262,58 +313,162 @@ brick_deposit_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* 
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int d = 0; d < 2; ++d)
-            atomicAdd(&tile[lat][((c.lx + 1 + a) * BT + (c.ly + 1 + b)) * BT + (c.lz + 1 + d)], (wx[a] * wy[b]) * wz[d]);
+            if (ablate & 1) sink += (wx[a] * wy[b]) * wz[d] * (double)(((c.lx + 1 + a) * BT + (c.ly + 1 + b)) * BT + (c.lz + 1 + d));
+            else atomicAdd(&tile[lat][((c.lx + 1 + a) * BT + (c.ly + 1 + b)) * BT + (c.lz + 1 + d)], (wx[a] * wy[b]) * wz[d]);
     }
   }
+  if (sink == 1.2345e300) tile[0][0] = sink;
   __syncthreads();
+  if (ablate & 2) { if (tile[0][threadIdx.x] == 1.2345e300) grid[0] = 1.0; return; }
+  if (stage) {                                             // the whole tile, as it is, to this chunk's slot: brick_assemble_kernel sums the slots
+    double* out = stage + (size_t)blockIdx.x * (2 * BT3);
+    for (int t = threadIdx.x; t < BT3; t += 256) { out[t] = tile[0][t]; if (interlace) out[BT3 + t] = tile[1][t]; }
+    return;
+  }
   for (int t = threadIdx.x; t < BT3; t += 256) {
     const double v0 = tile[0][t], v1 = tile[1][t];
     if (v0 == 0.0 && v1 == 0.0) continue;
-    const int gx = wrap_index(ox - 1 + t / (BT * BT), N), gy = wrap_index(oy - 1 + (t / BT) % BT, N), gz = wrap_index(oz - 1 + t % BT, N);
+    const int gx = wrap_near(ox - 1 + t / (BT * BT), N), gy = wrap_near(oy - 1 + (t / BT) % BT, N), gz = wrap_near(oz - 1 + t % BT, N);
     double* cell = grid + 2 * (((size_t)gx * N + gy) * N + gz);
     if (v0 != 0.0) atomicAdd(cell, v0);
     if (v1 != 0.0) atomicAdd(cell + 1, v1);
   }
 }
 
+// The density grid from the staged tiles, without atomics and without clearing it first: one block per brick writes the brick's own 8^3 cells
+// (both lattices: re, im), each the sum — in a fixed order — of that cell in the tiles of every chunk of every brick whose tile covers it:
+// the brick itself and, for the cells on its low / high faces, the neighbour below (whose tile reaches one cell above its brick: local 8)
+// / above (local -1). Needs a mesh of whole bricks (N a multiple of 8); other meshes keep the atomic flush of brick_deposit_kernel.
+// At 256^3 particles on a 256^3 mesh the atomic flush was 0.6 of the deposit's 0.84 ms (65 M global fp64 atomics) plus 0.075 ms of clearing.
+__global__ void __launch_bounds__(256)
+brick_assemble_kernel(const double* __restrict__ stage, const int* __restrict__ chunk_off, int nbr, int N, int interlace,
+                      double2* __restrict__ grid) {
+  __shared__ int coff[27][2];                                  // chunk ranges of the 27 bricks around this one
+  const int brick = blockIdx.x;
+  const int bx = brick / (nbr * nbr), by = (brick / nbr) % nbr, bz = brick % nbr;
+  if (threadIdx.x < 27) {
+    const int da = (int)threadIdx.x / 9 - 1, db = ((int)threadIdx.x / 3) % 3 - 1, dd = (int)threadIdx.x % 3 - 1;
+    int sx = bx + da, sy = by + db, sz = bz + dd;
+    sx = sx < 0 ? sx + nbr : (sx >= nbr ? sx - nbr : sx); sy = sy < 0 ? sy + nbr : (sy >= nbr ? sy - nbr : sy); sz = sz < 0 ? sz + nbr : (sz >= nbr ? sz - nbr : sz);
+    const int src = (sx * nbr + sy) * nbr + sz;
+    const int c0 = chunk_off[src], c1 = chunk_off[src + 1];
+    const bool heavy = c1 - c0 > BHEAVY;                       // a crowded brick's chunks add their tiles themselves, afterwards (atomics)
+    coff[threadIdx.x][0] = heavy ? 0 : c0; coff[threadIdx.x][1] = heavy ? 0 : c1;
+  }
+  __syncthreads();
+  constexpr int CPT = BR * BR * BR / 256;                      // cells per thread
+  double v0[CPT], v1[CPT];
+  int k0[CPT][8], k1[CPT][8], tt[CPT][8];
+  // first the first chunk of each of the (up to eight) covering bricks, all loads in flight together: the usual case is one chunk per brick
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+    const int cell = (int)threadIdx.x + 256 * u;
+    const int a = cell / (BR * BR), b = (cell / BR) % BR, d = cell % BR;
+    const int na = a == 0 ? -1 : (a == BR - 1 ? 1 : 0), nb = b == 0 ? -1 : (b == BR - 1 ? 1 : 0), nd = d == 0 ? -1 : (d == BR - 1 ? 1 : 0);
+    double f0[8], f1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ia = j >> 2, ib = (j >> 1) & 1, id = j & 1;
+      const bool covered = (!ia || na) && (!ib || nb) && (!id || nd);
+      const int da = ia ? na : 0, db = ib ? nb : 0, dd = id ? nd : 0;
+      const int w = (da + 1) * 9 + (db + 1) * 3 + (dd + 1);
+      k0[u][j] = covered ? coff[w][0] : 0; k1[u][j] = covered ? coff[w][1] : 0;
+      tt[u][j] = ((a - BR * da + 1) * BT + (b - BR * db + 1)) * BT + (d - BR * dd + 1);
+      const bool has = k0[u][j] < k1[u][j];
+      const double* in = stage + (size_t)k0[u][j] * (2 * BT3) + tt[u][j];
+      f0[j] = has ? in[0] : 0.0;
+      f1[j] = has && interlace ? in[BT3] : 0.0;
+    }
+    v0[u] = 0.0; v1[u] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v0[u] += f0[j]; v1[u] += f1[j]; }
+  }
+  // then whatever further chunks a crowded brick has (fixed order)
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      for (int k = k0[u][j] + 1; k < k1[u][j]; ++k) {
+        const double* in = stage + (size_t)k * (2 * BT3) + tt[u][j];
+        v0[u] += in[0];
+        if (interlace) v1[u] += in[BT3];
+      }
+    const int cell = (int)threadIdx.x + 256 * u;
+    const int a = cell / (BR * BR), b = (cell / BR) % BR, d = cell % BR;
+    grid[((size_t)(bx * BR + a) * N + (by * BR + b)) * N + (bz * BR + d)] = make_double2(v0[u], v1[u]);
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 brick_gather_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z,
-                    const uint32_t* __restrict__ idx_s, const int* __restrict__ brick_start, const int* __restrict__ chunk_off,
-                    int nb3, int nbr, double invh, int N, const double2* __restrict__ f1, const double2* __restrict__ f2,
-                    const double2* __restrict__ f3, int interlace, T* __restrict__ ax, T* __restrict__ ay, T* __restrict__ az) {
-  __shared__ double tile[6][BT3];        // g_x g_y g_z on lattice 1, then on lattice 2
+                    const uint32_t* __restrict__ idx_s, const int4* __restrict__ chunk_info,
+                    int nbr, double invh, int N, const double2* __restrict__ f1, const double2* __restrict__ f2,
+                    const double2* __restrict__ f3, int interlace, T* __restrict__ ax, T* __restrict__ ay, T* __restrict__ az, int ablate) {
+  // g_x g_y g_z on lattice 1, then on lattice 2 — in the OUTPUT precision: an fp32 context interpolates in fp32 (the cell fractions still come
+  // from fp64 arithmetic on the coordinates): 24 KB of LDS instead of 48 (six blocks per CU instead of three) and a third of the fp64
+  // instructions, which run at half the fp32 rate — the kernel was bound by them, not by memory (ablation: DESIGN.md §6.7)
+  __shared__ T tile[6][BT3];
   int brick, p0, p1;
-  if (!brick_of_block(brick_start, chunk_off, nb3, brick, p0, p1)) return;
+  if (!brick_of_block(chunk_info, (int)blockIdx.x, brick, p0, p1)) return;
   const int ox = (brick / (nbr * nbr)) * BR, oy = ((brick / nbr) % nbr) * BR, oz = (brick % nbr) * BR;
-  for (int t = threadIdx.x; t < BT3; t += 256) {
-    const int gx = wrap_index(ox - 1 + t / (BT * BT), N), gy = wrap_index(oy - 1 + (t / BT) % BT, N), gz = wrap_index(oz - 1 + t % BT, N);
-    const size_t cell = ((size_t)gx * N + gy) * N + gz;
-    const double2 a = f1[cell], b = f2[cell];
-    tile[0][t] = a.x; tile[1][t] = a.y; tile[2][t] = b.x;
-    if (interlace) { const double2 c = f3[cell]; tile[3][t] = b.y; tile[4][t] = c.x; tile[5][t] = c.y; }
+  uint32_t q[BPT];
+  T px[BPT], py[BPT], pz[BPT];
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) { const int p = p0 + u * 256 + (int)threadIdx.x; q[u] = p < p1 ? ((ablate & 32) ? (uint32_t)p : idx_s[p]) : 0u; }
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) {
+    const bool live = p0 + u * 256 + (int)threadIdx.x < p1;
+    px[u] = live ? x[q[u]] : T(0); py[u] = live ? y[q[u]] : T(0); pz[u] = live ? z[q[u]] : T(0);
+  }
+  if (!(ablate & 8)) {
+    constexpr int TPT = (BT3 + 255) / 256;
+    double2 fa[TPT], fb[TPT], fc[TPT];
+#pragma unroll
+    for (int u = 0; u < TPT; ++u) {
+      const int t = (int)threadIdx.x + 256 * u;
+      if (t < BT3) {
+        const int gx = wrap_near(ox - 1 + t / (BT * BT), N), gy = wrap_near(oy - 1 + (t / BT) % BT, N), gz = wrap_near(oz - 1 + t % BT, N);
+        const size_t cell = ((size_t)gx * N + gy) * N + gz;
+        fa[u] = f1[cell]; fb[u] = f2[cell];
+        if (interlace) fc[u] = f3[cell];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TPT; ++u) {
+      const int t = (int)threadIdx.x + 256 * u;
+      if (t < BT3) {
+        tile[0][t] = (T)fa[u].x; tile[1][t] = (T)fa[u].y; tile[2][t] = (T)fb[u].x;
+        if (interlace) { tile[3][t] = (T)fb[u].y; tile[4][t] = (T)fc[u].x; tile[5][t] = (T)fc[u].y; }
+      }
+    }
   }
   __syncthreads();
-  for (int p = p0 + (int)threadIdx.x; p < p1; p += 256) {
-    const uint32_t q = idx_s[p];
-    const T px = x[q], py = y[q], pz = z[q];
-    double sx = 0.0, sy = 0.0, sz = 0.0;
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) {
+    if (p0 + u * 256 + (int)threadIdx.x >= p1) break;
+    T sx = 0, sy = 0, sz = 0;
+    const cic_both cb = cic_in_brick(px[u], py[u], pz[u], invh, N, ox, oy, oz);
     for (int lat = 0; lat < (interlace ? 2 : 1); ++lat) {
-      const cic_local c = cic_in_brick(px, py, pz, invh, N, ox, oy, oz, lat);
-      const double wx[2] = {1.0 - c.wx, c.wx}, wy[2] = {1.0 - c.wy, c.wy}, wz[2] = {1.0 - c.wz, c.wz};
+      const cic_local c = cic_lattice(cb, lat);
+      const T wx[2] = {(T)(1.0 - c.wx), (T)c.wx}, wy[2] = {(T)(1.0 - c.wy), (T)c.wy}, wz0 = (T)(1.0 - c.wz), wz1 = (T)c.wz;
+      const int tb = ((c.lx + 1) * BT + (c.ly + 1)) * BT + (c.lz + 1);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const int t = ((c.lx + 1 + a) * BT + (c.ly + 1 + b)) * BT + (c.lz + 1 + d);
-            const double w = (wx[a] * wy[b]) * wz[d];
-            sx += w * tile[3 * lat][t]; sy += w * tile[3 * lat + 1][t]; sz += w * tile[3 * lat + 2][t];
+        for (int b = 0; b < 2; ++b) {
+          const int t = tb + (a * BT + b) * BT;               // the two cells along z are neighbours in the tile: one two-word read each
+          const T w = wx[a] * wy[b];
+          if (ablate & 16) { sx += w * (T)t; sy += w; sz -= w; }
+          else {
+            sx += w * (wz0 * tile[3 * lat][t] + wz1 * tile[3 * lat][t + 1]);
+            sy += w * (wz0 * tile[3 * lat + 1][t] + wz1 * tile[3 * lat + 1][t + 1]);
+            sz += w * (wz0 * tile[3 * lat + 2][t] + wz1 * tile[3 * lat + 2][t + 1]);
           }
+        }
     }
-    const double sc = interlace ? 0.5 : 1.0;
-    ax[q] = (T)(sc * sx); ay[q] = (T)(sc * sy); az[q] = (T)(sc * sz);
+    const T sc = interlace ? (T)0.5 : (T)1;
+    ax[q[u]] = sc * sx; ay[q[u]] = sc * sy; az[q[u]] = sc * sz;
   }
 }
 
@@ -1008,6 +1163,14 @@ int brick_prepare(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* 
   tb = s.tmp_bytes;
   NB_HIP(c, rocprim::exclusive_scan(s.tmp, tb, s.chunk_cnt, s.chunk_off, 0, (size_t)nb3 + 1, rocprim::plus<int>(), st));
   max_chunks = (int64_t)nb3 + n / BCH + 1;
+  if (s.chunk_info_cap < max_chunks) {
+    NB_HIP(c, hipStreamSynchronize(st));
+    if (s.chunk_info) { (void)hipFree(s.chunk_info); s.chunk_info = nullptr; s.chunk_info_cap = 0; }
+    NB_HIP(c, hipMalloc((void**)&s.chunk_info, (size_t)(max_chunks + max_chunks / 8) * sizeof(int4)));
+    s.chunk_info_cap = max_chunks + max_chunks / 8;
+  }
+  chunk_info_kernel<<<(unsigned)((max_chunks + 255) / 256), 256, 0, st>>>(s.cell_start, s.chunk_off, nb3, 1, BCH, (int)max_chunks, s.chunk_info);
+  NB_HIP(c, hipGetLastError());
   return NB_OK;
 }
 
@@ -1023,11 +1186,34 @@ int long_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z, 
   int nbr = 0, nb3 = 0;
   int64_t max_chunks = 0;
   if (bricks) { int rc = brick_prepare<T>(c, s, x, y, z, n, 1.0 / h, ngrid, nbr, nb3, max_chunks); if (rc) return rc; }
-  NB_HIP(c, hipMemsetAsync(s.grid[0], 0, cells * sizeof(hipfftDoubleComplex), st));
+  static const int ablate = getenv("NB_MESH_ABLATE") ? atoi(getenv("NB_MESH_ABLATE")) : 0;
+  // a mesh of whole bricks: the tiles go to one slot per chunk and a second kernel sums them into the grid (no atomics, no clearing);
+  // NB_MESH_STAGE=0 keeps the atomic flush
+  static const bool stage_env = !(getenv("NB_MESH_STAGE") && atoi(getenv("NB_MESH_STAGE")) == 0);
+  const bool staged = bricks && stage_env && ngrid % BR == 0;
+  if (staged && s.stage_cap < max_chunks) {
+    NB_HIP(c, hipStreamSynchronize(st));
+    if (s.stage) { (void)hipFree(s.stage); s.stage = nullptr; s.stage_cap = 0; }
+    NB_HIP(c, hipMalloc((void**)&s.stage, (size_t)(max_chunks + max_chunks / 8) * 2 * BT3 * sizeof(double)));
+    s.stage_cap = max_chunks + max_chunks / 8;
+  }
+  if (!staged) NB_HIP(c, hipMemsetAsync(s.grid[0], 0, cells * sizeof(hipfftDoubleComplex), st));
   if (bricks) {
-    brick_deposit_kernel<T><<<(unsigned)max_chunks, 256, 0, st>>>(x, y, z, m, s.idx_s, s.cell_start, s.chunk_off, nb3, nbr, 1.0 / h, ngrid,
-                                                                 interlace, (double*)s.grid[0]);
+    // staged: the chunks of ordinary bricks leave their tiles in `stage`, brick_assemble_kernel writes every grid cell from them, and only then
+    // the chunks of crowded bricks (strong clustering: summing thousands of tiles one after the other in the one block that owns the cells
+    // would serialise the heaviest part) add theirs with atomics
+    brick_deposit_kernel<T><<<(unsigned)max_chunks, 256, 0, st>>>(x, y, z, m, s.idx_s, s.chunk_info, nbr, 1.0 / h, ngrid, interlace,
+                                                                 (double*)s.grid[0], staged ? s.stage : nullptr, s.chunk_off, staged ? 1 : 0, ablate);
     NB_HIP(c, hipGetLastError());
+    if (staged) {
+      brick_assemble_kernel<<<nb3, 256, 0, st>>>(s.stage, s.chunk_off, nbr, ngrid, interlace, (double2*)s.grid[0]);
+      NB_HIP(c, hipGetLastError());
+      if (n > (int64_t)BHEAVY * BCH) {                       // (no brick can be crowded with fewer particles than that)
+        brick_deposit_kernel<T><<<(unsigned)max_chunks, 256, 0, st>>>(x, y, z, m, s.idx_s, s.chunk_info, nbr, 1.0 / h, ngrid, interlace,
+                                                                     (double*)s.grid[0], nullptr, s.chunk_off, 2, ablate);
+        NB_HIP(c, hipGetLastError());
+      }
+    }
   } else {
     for (int lat = 0; lat < (interlace ? 2 : 1); ++lat) {
       mesh_deposit_kernel<T><<<stream_grid(n), 256, 0, st>>>(x, y, z, m, n, 1.0 / h, ngrid, lat ? 0.5 : 0.0, lat, (double*)s.grid[0]);
@@ -1041,9 +1227,9 @@ int long_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z, 
   NB_HIP(c, hipGetLastError());
   for (int g = 1; g <= (interlace ? 3 : 2); ++g) M_FFT(c, hipfftExecZ2Z(s.fft, s.grid[g], s.grid[g], HIPFFT_BACKWARD));
   if (bricks)
-    brick_gather_kernel<T><<<(unsigned)max_chunks, 256, 0, st>>>(x, y, z, s.idx_s, s.cell_start, s.chunk_off, nb3, nbr, 1.0 / h, ngrid,
+    brick_gather_kernel<T><<<(unsigned)max_chunks, 256, 0, st>>>(x, y, z, s.idx_s, s.chunk_info, nbr, 1.0 / h, ngrid,
                                                                 (const double2*)s.grid[1], (const double2*)s.grid[2],
-                                                                (const double2*)s.grid[3], interlace, ax, ay, az);
+                                                                (const double2*)s.grid[3], interlace, ax, ay, az, ablate);
   else
     mesh_gather_kernel<T><<<stream_grid(n), 256, 0, st>>>(x, y, z, n, 1.0 / h, ngrid, (const double*)s.grid[1], (const double*)s.grid[2],
                                                           (const double*)s.grid[3], interlace, ax, ay, az);
@@ -1074,7 +1260,7 @@ void nb_mesh_release(nb_ctx* c) {
   for (auto& g : s.grid) if (g) (void)hipFree(g);
   if (s.have_fft) (void)hipfftDestroy(s.fft);
   for (void* p : {(void*)s.keys, (void*)s.keys_s, (void*)s.idx, (void*)s.idx_s, s.sorted, (void*)s.cell_start,
-                  (void*)s.chunk_cnt, (void*)s.chunk_off, s.tmp, (void*)s.table, (void*)s.chunk_info, (void*)s.ltab})
+                  (void*)s.chunk_cnt, (void*)s.chunk_off, s.tmp, (void*)s.table, (void*)s.chunk_info, (void*)s.ltab, (void*)s.stage})
     if (p) (void)hipFree(p);
   delete c->mesh;
   c->mesh = nullptr;

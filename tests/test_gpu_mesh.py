@@ -159,10 +159,13 @@ def test_steps_wrap_positions_and_track_the_ewald_trajectory(dtype):
     assert rms(d) < 0.05 * rms(by_force)          # same trajectories up to the sub-percent force error of the mesh
 
 
-@pytest.mark.parametrize("ngrid,interlace,dtype", [(27, True, np.float64), (50, False, np.float64), (64, True, np.float32), (9, True, np.float64)])
+@pytest.mark.parametrize("ngrid,interlace,dtype", [(27, True, np.float64), (50, False, np.float64), (64, True, np.float32), (9, True, np.float64),
+                                                   (32, True, np.float64), (40, False, np.float64), (8, True, np.float64), (16, False, np.float32)])
 def test_long_range_through_lds_bricks_matches_oracle(ngrid, interlace, dtype):
     """n >= 1e5 takes the brick-sorted, LDS-privatised deposit and gather: mesh sizes that are not multiples of the 8-cell brick,
-    a mesh smaller than one brick tile, particles far outside the box, clustered (one brick holds a third of the particles)."""
+    a mesh smaller than one brick tile, particles far outside the box, clustered (one brick holds a third of the particles). Meshes of whole
+    bricks (64, 32, 40, 16, and 8 = a single brick that is its own neighbour) take the staged deposit — tiles to one slot per chunk, summed by
+    brick_assemble_kernel — the others the atomic flush."""
     L, n = 75.0, 120_000
     rng = np.random.default_rng(ngrid)
     pos = rng.uniform(-L, 2 * L, (n, 3))

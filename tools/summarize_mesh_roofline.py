@@ -5,7 +5,9 @@ cell holding the two interlaced lattices):
   brick_key        12 n read (positions) + 4 n written (keys)                                    [+ 4 n index]
   radix sort       (4 + 4) n read + (4 + 4) n written, once                                      (rocPRIM: several passes — its own overhead)
   sort_gather      4 n (index) + 16 n gathered + 16 n written
-  brick_deposit    16 n read + 16 c written (the grid is cleared by a fill: + 16 c)
+  brick_deposit    16 n read + 16 c written — the deposit kernels AND brick_assemble_kernel (meshes of whole bricks: the tiles go through one
+                   staging slot per chunk and the grid is written once, not cleared and not touched by atomics; other meshes: a fill clears
+                   the grid, + 16 c, and the tiles are flushed with atomics)
   FFT (4 x 3-D)    a 3-D transform of a grid that does not fit in cache is three axis passes: 3 x (16 c read + 16 c written) each
   k-space          16 c read + 48 c written
   brick_gather     16 n read + 48 c read (three packed force grids) + 12 n written
@@ -21,7 +23,7 @@ groups = [
     ("radix_sort (rocPRIM)", lambda s: "rocprim" in s.lower(), 16 * n),
     ("sort_gather", lambda s: "sort_gather_kernel" in s, 36 * n),
     ("grid clear (fill)", lambda s: "fillBuffer" in s, 16 * c),
-    ("brick_deposit", lambda s: "brick_deposit_kernel" in s or "mesh_deposit_kernel" in s, 16 * n + 16 * c),
+    ("brick_deposit (+ assemble)", lambda s: "brick_deposit_kernel" in s or "mesh_deposit_kernel" in s or "brick_assemble_kernel" in s, 16 * n + 16 * c),
     ("fft (1 forward + 3 inverse, 3 axis passes each)", lambda s: s.startswith("fft_") or "transpose_rtc" in s, 4 * 3 * 32 * c),
     ("k-space", lambda s: "mesh_kspace_kernel" in s, 64 * c),
     ("brick_gather", lambda s: "brick_gather_kernel" in s or "mesh_gather_kernel" in s, 16 * n + 48 * c + 12 * n),
