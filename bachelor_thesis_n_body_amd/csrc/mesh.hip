@@ -272,14 +272,14 @@ constexpr int BHEAVY = 8;           // a brick with more chunks than this is "cr
 
 // Both brick kernels are made of short blocks (<= 1024 particles, two or three dependent trips to memory each): what they cost is latency
 // unless every load a block needs is in flight at once — so a thread first fetches the indices and then the coordinates of ALL its
-// particles, and only then touches the tile (zeroing it / filling it with 12 loads per thread in flight); measured at 256^3 on a 256^3
-// mesh: gather 0.75 -> see DESIGN.md §6.7.
+// particles, and only then touches the tile (zeroing it / filling it with 12 loads per thread in flight); 256^3 particles on a 256^3
+// mesh: gather 0.71 -> 0.61 ms (profiles/r04_mesh_brick_kernels_ablation.txt).
 template <typename T>
 __global__ void __launch_bounds__(256)
 brick_deposit_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z, const T* __restrict__ m,
                      const uint32_t* __restrict__ idx_s, const int4* __restrict__ chunk_info,
                      int nbr, double invh, int N, int interlace, double* __restrict__ grid, double* __restrict__ stage,
-                     const int* __restrict__ chunk_off, int which, int ablate) {
+                     const int* __restrict__ chunk_off, int which) {
   __shared__ double tile[2][BT3];
   int brick, p0, p1;
   if (!brick_of_block(chunk_info, (int)blockIdx.x, brick, p0, p1)) return;
@@ -290,7 +290,7 @@ brick_deposit_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* 
   uint32_t q[BPT];
   T px[BPT], py[BPT], pz[BPT], pm[BPT];
 #pragma unroll
-  for (int u = 0; u < BPT; ++u) { const int p = p0 + u * 256 + (int)threadIdx.x; q[u] = p < p1 ? ((ablate & 4) ? (uint32_t)p : idx_s[p]) : 0u; }
+  for (int u = 0; u < BPT; ++u) { const int p = p0 + u * 256 + (int)threadIdx.x; q[u] = p < p1 ? idx_s[p] : 0u; }
 #pragma unroll
   for (int u = 0; u < BPT; ++u) {
     const bool live = p0 + u * 256 + (int)threadIdx.x < p1;
@@ -298,7 +298,6 @@ brick_deposit_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* 
   }
   for (int t = threadIdx.x; t < BT3; t += 256) { tile[0][t] = 0.0; tile[1][t] = 0.0; }
   __syncthreads();
-  double sink = 0.0;
 #pragma unroll
   for (int u = 0; u < BPT; ++u) {
     if (p0 + u * 256 + (int)threadIdx.x >= p1) break;
@@ -313,13 +312,10 @@ brick_deposit_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* 
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int d = 0; d < 2; ++d)
-            if (ablate & 1) sink += (wx[a] * wy[b]) * wz[d] * (double)(((c.lx + 1 + a) * BT + (c.ly + 1 + b)) * BT + (c.lz + 1 + d));
-            else atomicAdd(&tile[lat][((c.lx + 1 + a) * BT + (c.ly + 1 + b)) * BT + (c.lz + 1 + d)], (wx[a] * wy[b]) * wz[d]);
+            atomicAdd(&tile[lat][((c.lx + 1 + a) * BT + (c.ly + 1 + b)) * BT + (c.lz + 1 + d)], (wx[a] * wy[b]) * wz[d]);
     }
   }
-  if (sink == 1.2345e300) tile[0][0] = sink;
   __syncthreads();
-  if (ablate & 2) { if (tile[0][threadIdx.x] == 1.2345e300) grid[0] = 1.0; return; }
   if (stage) {                                             // the whole tile, as it is, to this chunk's slot: brick_assemble_kernel sums the slots
     double* out = stage + (size_t)blockIdx.x * (2 * BT3);
     for (int t = threadIdx.x; t < BT3; t += 256) { out[t] = tile[0][t]; if (interlace) out[BT3 + t] = tile[1][t]; }
@@ -404,7 +400,7 @@ __global__ void __launch_bounds__(256)
 brick_gather_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ z,
                     const uint32_t* __restrict__ idx_s, const int4* __restrict__ chunk_info,
                     int nbr, double invh, int N, const double2* __restrict__ f1, const double2* __restrict__ f2,
-                    const double2* __restrict__ f3, int interlace, T* __restrict__ ax, T* __restrict__ ay, T* __restrict__ az, int ablate) {
+                    const double2* __restrict__ f3, int interlace, T* __restrict__ ax, T* __restrict__ ay, T* __restrict__ az) {
   // g_x g_y g_z on lattice 1, then on lattice 2 — in the OUTPUT precision: an fp32 context interpolates in fp32 (the cell fractions still come
   // from fp64 arithmetic on the coordinates): 24 KB of LDS instead of 48 (six blocks per CU instead of three) and a third of the fp64
   // instructions, which run at half the fp32 rate — the kernel was bound by them, not by memory (ablation: DESIGN.md §6.7)
@@ -415,13 +411,13 @@ brick_gather_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* _
   uint32_t q[BPT];
   T px[BPT], py[BPT], pz[BPT];
 #pragma unroll
-  for (int u = 0; u < BPT; ++u) { const int p = p0 + u * 256 + (int)threadIdx.x; q[u] = p < p1 ? ((ablate & 32) ? (uint32_t)p : idx_s[p]) : 0u; }
+  for (int u = 0; u < BPT; ++u) { const int p = p0 + u * 256 + (int)threadIdx.x; q[u] = p < p1 ? idx_s[p] : 0u; }
 #pragma unroll
   for (int u = 0; u < BPT; ++u) {
     const bool live = p0 + u * 256 + (int)threadIdx.x < p1;
     px[u] = live ? x[q[u]] : T(0); py[u] = live ? y[q[u]] : T(0); pz[u] = live ? z[q[u]] : T(0);
   }
-  if (!(ablate & 8)) {
+  {
     constexpr int TPT = (BT3 + 255) / 256;
     double2 fa[TPT], fb[TPT], fc[TPT];
 #pragma unroll
@@ -459,12 +455,9 @@ brick_gather_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* _
         for (int b = 0; b < 2; ++b) {
           const int t = tb + (a * BT + b) * BT;               // the two cells along z are neighbours in the tile: one two-word read each
           const T w = wx[a] * wy[b];
-          if (ablate & 16) { sx += w * (T)t; sy += w; sz -= w; }
-          else {
-            sx += w * (wz0 * tile[3 * lat][t] + wz1 * tile[3 * lat][t + 1]);
-            sy += w * (wz0 * tile[3 * lat + 1][t] + wz1 * tile[3 * lat + 1][t + 1]);
-            sz += w * (wz0 * tile[3 * lat + 2][t] + wz1 * tile[3 * lat + 2][t + 1]);
-          }
+          sx += w * (wz0 * tile[3 * lat][t] + wz1 * tile[3 * lat][t + 1]);
+          sy += w * (wz0 * tile[3 * lat + 1][t] + wz1 * tile[3 * lat + 1][t + 1]);
+          sz += w * (wz0 * tile[3 * lat + 2][t] + wz1 * tile[3 * lat + 2][t + 1]);
         }
     }
     const T sc = interlace ? (T)0.5 : (T)1;
@@ -1186,7 +1179,6 @@ int long_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z, 
   int nbr = 0, nb3 = 0;
   int64_t max_chunks = 0;
   if (bricks) { int rc = brick_prepare<T>(c, s, x, y, z, n, 1.0 / h, ngrid, nbr, nb3, max_chunks); if (rc) return rc; }
-  static const int ablate = getenv("NB_MESH_ABLATE") ? atoi(getenv("NB_MESH_ABLATE")) : 0;
   // a mesh of whole bricks: the tiles go to one slot per chunk and a second kernel sums them into the grid (no atomics, no clearing);
   // NB_MESH_STAGE=0 keeps the atomic flush
   static const bool stage_env = !(getenv("NB_MESH_STAGE") && atoi(getenv("NB_MESH_STAGE")) == 0);
@@ -1203,14 +1195,14 @@ int long_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z, 
     // the chunks of crowded bricks (strong clustering: summing thousands of tiles one after the other in the one block that owns the cells
     // would serialise the heaviest part) add theirs with atomics
     brick_deposit_kernel<T><<<(unsigned)max_chunks, 256, 0, st>>>(x, y, z, m, s.idx_s, s.chunk_info, nbr, 1.0 / h, ngrid, interlace,
-                                                                 (double*)s.grid[0], staged ? s.stage : nullptr, s.chunk_off, staged ? 1 : 0, ablate);
+                                                                 (double*)s.grid[0], staged ? s.stage : nullptr, s.chunk_off, staged ? 1 : 0);
     NB_HIP(c, hipGetLastError());
     if (staged) {
       brick_assemble_kernel<<<nb3, 256, 0, st>>>(s.stage, s.chunk_off, nbr, ngrid, interlace, (double2*)s.grid[0]);
       NB_HIP(c, hipGetLastError());
       if (n > (int64_t)BHEAVY * BCH) {                       // (no brick can be crowded with fewer particles than that)
         brick_deposit_kernel<T><<<(unsigned)max_chunks, 256, 0, st>>>(x, y, z, m, s.idx_s, s.chunk_info, nbr, 1.0 / h, ngrid, interlace,
-                                                                     (double*)s.grid[0], nullptr, s.chunk_off, 2, ablate);
+                                                                     (double*)s.grid[0], nullptr, s.chunk_off, 2);
         NB_HIP(c, hipGetLastError());
       }
     }
@@ -1229,7 +1221,7 @@ int long_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z, 
   if (bricks)
     brick_gather_kernel<T><<<(unsigned)max_chunks, 256, 0, st>>>(x, y, z, s.idx_s, s.chunk_info, nbr, 1.0 / h, ngrid,
                                                                 (const double2*)s.grid[1], (const double2*)s.grid[2],
-                                                                (const double2*)s.grid[3], interlace, ax, ay, az, ablate);
+                                                                (const double2*)s.grid[3], interlace, ax, ay, az);
   else
     mesh_gather_kernel<T><<<stream_grid(n), 256, 0, st>>>(x, y, z, n, 1.0 / h, ngrid, (const double*)s.grid[1], (const double*)s.grid[2],
                                                           (const double*)s.grid[3], interlace, ax, ay, az);
