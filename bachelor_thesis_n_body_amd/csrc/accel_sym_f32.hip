@@ -27,6 +27,7 @@
 //    takes 0.45 ms of a ~160 ms launch, the writes hide behind the math.
 //  * accuracy as accel_f32: fp32 partial sums live for one tile (sinks) / one set of 256*KS sinks (sources) and are then widened.
 #include "nb_common.h"
+#include <cmath>
 #include "../../include/nbody_amd.h"
 #include <cstdio>
 #include <cstdlib>
@@ -179,8 +180,8 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
   // the pair finishes 10 % later than two waves sharing fairly would. So the two waves take TURNS at the raised priority: time slices of
   // 2^turn_shift ticks of the constant-rate counter (100 MHz, the same for every wave of the device), the wave whose slot id has the slice's
   // parity runs at s_setprio 1, the other at 0. The counter is read when a chunk of 8 steps begins and acted on when it ends (scalar work
-  // outside the step loop). The slice must be long against that look-up period: 2^14 ticks = 164 us (per CU 667 against 727 us, launch 819 ->
-  // 776 us; 2^12: 613 / 742). First attempts failed for exactly that reason — turns counted in each wave's OWN steps let the leader reach
+  // outside the step loop). The slice must be long against that look-up period and short against the launch (the host chooses it:
+  // auto_turn_shift); N = 65 536 with 2^14 ticks = 164 us: per CU 667 against 727 us, launch 819 -> 776 us. First attempts failed for exactly that reason — turns counted in each wave's OWN steps let the leader reach
   // its next favoured segment first (63 : 37), slices of 10 us looked at every 32 steps (~20-40 us) left the two priorities uncorrelated
   // (profiles/r04_priority_turns_between_coresident_waves.txt). Pinning the step's LDS reads above its arithmetic does not make a lone wave faster.
   // The turn is the BLOCK's, not the wave's: all four waves of a block must be favoured in the same slices (they meet at every tile's barrier,
@@ -464,6 +465,16 @@ accel_sym_reduce_f32_kernel(const double* __restrict__ part, long long G, int nb
   }
 }
 
+// Slice length of the priority turns (the kernel's turn_shift: slices of 2^shift ticks of the 100 MHz counter) for blocks expected to run for
+// `block_ticks`: a third of that, to the nearest power of two. Measured (bench.py --n N on one box, profiles/r04_turn_shift_sweep.txt): the best
+// slice grows with the launch — 2^11..12 at N = 24 576 (0.15 ms), 2^12 at 32 768, 2^14 at 49 152 ... 65 536, 2^15 at 98 304 ... 131 072: a
+// short launch needs several turns to be fair at all, a long one loses a little with every change of hands. Launches of many rounds are
+// indifferent (a CU always holds two blocks there).
+int auto_turn_shift(double block_ticks) {
+  const int s = (int)std::lround(std::log2(std::max(block_ticks / 3.0, 1.0)));
+  return std::min(22, std::max(10, s));
+}
+
 long long env_ll(const char* name, long long dflt) {
   const char* v = getenv(name);
   return v && *v ? atoll(v) : dflt;
@@ -563,7 +574,8 @@ int run_sym(nb_ctx* c, const float* x, const float* y, const float* z, const flo
     long long* trace = nullptr;
     if (trace_path && *trace_path) NB_HIP(c, hipMalloc(&trace, (size_t)nblk * 3 * sizeof(long long)));
     kernel<<<nblk, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, nsets, H, o_begin, tps, Gs, eps2, part, slab, bslab, n_pad,
-                                          x, y, z, m, (int)n, nsets, n_pad, 0, 0, turn_shift, trace);
+                                          x, y, z, m, (int)n, nsets, n_pad, 0, 0,
+                                          turn_shift >= 0 ? turn_shift : auto_turn_shift((double)Gs / nblk * (KS / 2) * U * 7.3), trace);
     NB_HIP(c, hipGetLastError());
     if (trace) {
       std::vector<long long> h((size_t)nblk * 3);
@@ -633,7 +645,8 @@ int run_cross(nb_ctx* c, const float* xa, const float* ya, const float* za, cons
     const int nb_launch = std::min(nblk_max, sym_blocks(c, kernel, (long long)nb_sets * tps, env_blocks, env_rounds));
     if (nb_launch / nb_sets + 2 > nseg_max) return nb_fail(c, NB_ERR_ARG, "accel_sym_f32: internal slot count");
     kernel<<<nb_launch, BLOCK, 0, c->stream>>>(xa, ya, za, ma, (int)na, nsa, 0, 0, tps, Gs, eps2, part, slab, bslab, npa,
-                                               xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0, turn_shift, nullptr);
+                                               xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0,
+                                               turn_shift >= 0 ? turn_shift : auto_turn_shift((double)Gs / nb_launch * (KS / 2) * U * 7.3), nullptr);
     NB_HIP(c, hipGetLastError());
     accel_sym_boundary_f32_kernel<KS, U, TJ, POT><<<nb_launch, BLOCK, 0, c->stream>>>(slab, bslab, nsa, 0, 0, tps, Gs, nsb, npb, 1, b0);
     NB_HIP(c, hipGetLastError());
@@ -657,7 +670,7 @@ SymOpt sym_options(const nb_ctx* c) {
   static const long long env_mode = env_ll("NB_F32_SYM", 1), env_min_n = env_ll("NB_F32_SYM_MIN_N", 24576),
                          env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_blocks = env_ll("NB_F32_SYM_BLOCKS", 0),
                          env_rounds = env_ll("NB_F32_SYM_ROUNDS", 0), env_ks = env_ll("NB_F32_SYM_KS", 0),
-                         env_turn = env_ll("NB_F32_SYM_TURN_SHIFT", 14);     // priority turns: time slices of 2^14 ticks of the 100 MHz counter (164 us); 0 = off
+                         env_turn = env_ll("NB_F32_SYM_TURN_SHIFT", -1);     // priority turns: time slices of 2^shift ticks of the 100 MHz counter; -1 = from the launch (auto_turn_shift), 0 = off
   return SymOpt{c->sym_enable >= 0 ? c->sym_enable : env_mode, c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
                 c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_blocks, env_rounds, env_ks, env_turn};
 }

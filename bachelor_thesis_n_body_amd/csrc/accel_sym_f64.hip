@@ -13,6 +13,7 @@
 //  * per tile the waves' copies are added in a fixed order and stored to an fp64 slab [offset][3][n]; the sinks' sums go to a slab
 //    [group][3][n]; a second kernel adds everything in a fixed order. No atomics anywhere.
 #include "nb_common.h"
+#include <cmath>
 #include "../../include/nbody_amd.h"
 #include <algorithm>
 #include <cstdlib>
@@ -339,6 +340,16 @@ accel_sym_reduce_f64_kernel(const double* __restrict__ part, long long Gs, int n
   }
 }
 
+// Slice length of the priority turns (the kernel's turn_shift: slices of 2^shift ticks of the 100 MHz counter) for blocks expected to run for
+// `block_ticks`: a third of that, to the nearest power of two. Measured (bench.py --n N on one box, profiles/r04_turn_shift_sweep.txt): the best
+// slice grows with the launch — 2^11..12 at N = 24 576 (0.15 ms), 2^12 at 32 768, 2^14 at 49 152 ... 65 536, 2^15 at 98 304 ... 131 072: a
+// short launch needs several turns to be fair at all, a long one loses a little with every change of hands. Launches of many rounds are
+// indifferent (a CU always holds two blocks there).
+int auto_turn_shift(double block_ticks) {
+  const int s = (int)std::lround(std::log2(std::max(block_ticks / 3.0, 1.0)));
+  return std::min(22, std::max(10, s));
+}
+
 long long env_ll(const char* name, long long dflt) {
   const char* v = getenv(name);
   return v && *v ? atoll(v) : dflt;
@@ -425,7 +436,8 @@ int run_sym(nb_ctx* c, const double* x, const double* y, const double* z, const 
     const int nslots = std::max(0, s_end - s_begin);
     if (nblk / nsets + 2 > nseg_max) return nb_fail(c, NB_ERR_ARG, "accel_sym_f64: internal slot count");
     kernel<<<nblk, BLOCK, 0, c->stream>>>(x, y, z, m, (int)n, nsets, H, o_begin, tps, Gs, eps2, part, slab, bslab, n_pad,
-                                          x, y, z, m, (int)n, nsets, n_pad, 0, 0, turn_shift);
+                                          x, y, z, m, (int)n, nsets, n_pad, 0, 0,
+                                          turn_shift >= 0 ? turn_shift : auto_turn_shift((double)Gs / nblk * KS * 8.1));
     NB_HIP(c, hipGetLastError());
     // the tiles a block boundary cut are finished inside the reduce kernel; the last pass also applies the integrator tail, if one is armed
     const SymCut cut{nslots > 0 ? bslab : nullptr, nsets, o_begin, s_begin, tps, TJ, HS};
@@ -483,7 +495,8 @@ int run_cross(nb_ctx* c, const double* xa, const double* ya, const double* za, c
     const int nb_launch = std::min(nblk_max, sym_blocks(c, kernel, (long long)nb_sets * tps, env_blocks, env_rounds));
     if (nb_launch / nb_sets + 2 > nseg_max) return nb_fail(c, NB_ERR_ARG, "accel_sym_f64: internal slot count");
     kernel<<<nb_launch, BLOCK, 0, c->stream>>>(xa, ya, za, ma, (int)na, nsa, 0, 0, tps, Gs, eps2, part, slab, bslab, npa,
-                                               xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0, turn_shift);
+                                               xb, yb, zb, mb, (int)nb, nsb, npb, 1, b0,
+                                               turn_shift >= 0 ? turn_shift : auto_turn_shift((double)Gs / nb_launch * KS * 8.1));
     NB_HIP(c, hipGetLastError());
     accel_sym_boundary_f64_kernel<KS, TJ, POT><<<nb_launch, BLOCK, 0, c->stream>>>(slab, bslab, nsa, 0, 0, tps, Gs, nsb, npb, 1, b0);
     NB_HIP(c, hipGetLastError());
@@ -504,7 +517,7 @@ struct SymOpt { long long mode, min_n, budget, blocks, rounds, ks, turn; };
 SymOpt sym_options(const nb_ctx* c) {
   static const long long env_mode = env_ll("NB_F64_SYM", 1), env_min_n = env_ll("NB_F64_SYM_MIN_N", 16384),
                          env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_blocks = env_ll("NB_F64_SYM_BLOCKS", 0),
-                         env_rounds = env_ll("NB_F64_SYM_ROUNDS", 0), env_ks = env_ll("NB_F64_SYM_KS", 0), env_turn = env_ll("NB_F64_SYM_TURN_SHIFT", 14);
+                         env_rounds = env_ll("NB_F64_SYM_ROUNDS", 0), env_ks = env_ll("NB_F64_SYM_KS", 0), env_turn = env_ll("NB_F64_SYM_TURN_SHIFT", -1);    // -1: slice length from the launch (auto_turn_shift), 0: no turns
   return SymOpt{c->sym_enable >= 0 ? c->sym_enable : env_mode, c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
                 c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_blocks, env_rounds, env_ks, env_turn};
 }
