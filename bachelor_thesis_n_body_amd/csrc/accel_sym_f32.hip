@@ -56,8 +56,8 @@ template <bool UNIFORM> __device__ inline float4 ld_src(const float4* p) { retur
 // 8.02 rounds — the ninth, with 8 blocks, cost 6 % of the launch; at N = 65 536, 2176 one-tile blocks = 4.25 rounds cost 15 %.)
 // A block walks its tiles in order; when the sink set changes it stores the set's sink sums to slot (ordinal of this block among the blocks
 // that share the set) of the fp64 `part` slab and loads the next set. A tile cut by a block boundary is walked by two blocks: the one that
-// holds its step 0 writes the tile's source sums to the regular slab slot, the other to its own row of the `bslab`, which a small kernel adds
-// afterwards (B <= G / HS, so a tile is cut at most once). All of it is a fixed function of (n, B): bit-reproducible.
+// holds its step 0 writes the tile's source sums to the regular slab slot, the other to its own row of the `bslab`, which is added afterwards
+// (B <= G / HS, so a tile is cut at most once): a set on itself — by the reduce kernel; two different blocks — by a small kernel of its own. All of it is a fixed function of (n, B): bit-reproducible.
 __host__ __device__ inline long long part_begin(long long k, long long G, int B) { return k >= B ? G : ((k * G / B) & ~1LL); }
 __host__ __device__ inline int part_block_of(long long s, long long G, int B) {       // the block whose range holds step s
   int k = (int)(s * B / G);
@@ -346,7 +346,8 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
   if (trace && tid == 0) trace[3 * kb + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
-// slab entry of a tile cut by a block boundary += the share of the block that started inside it (one such block per tile: B <= G / HS)
+// two-block launches: slab entry of a tile cut by a block boundary += the share of the block that started inside it (one such block per tile:
+// B <= G / HS). A set on itself has this done by its reduce kernel.
 template <int KS, int U, int TJ, bool POT>
 __global__ void __launch_bounds__(BLOCK)
 accel_sym_boundary_f32_kernel(float* __restrict__ slab, const float* __restrict__ bslab, int nsets, int H, int o_begin, int tps, long long G,

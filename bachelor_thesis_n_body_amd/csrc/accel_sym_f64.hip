@@ -227,7 +227,7 @@ accel_sym_f64_kernel(const double* __restrict__ x, const double* __restrict__ y,
   if (cur >= 0) store_sinks(b0 + cur, seg);
 }
 
-// slab entry of a tile cut by a block boundary += the share of the block that started inside it
+// two-block launches: slab entry of a tile cut by a block boundary += the share of the block that started inside it (a set on itself: reduce kernel)
 template <int KS, int TJ, bool POT>
 __global__ void __launch_bounds__(BLOCK)
 accel_sym_boundary_f64_kernel(double* __restrict__ slab, const double* __restrict__ bslab, int nsets, int H, int o_begin, int tps, long long G,
