@@ -42,6 +42,14 @@ for n in [int(v) for v in sys.argv[1:]] or [65536]:
         idx = per_xcc[x]
         cus = collections.Counter((int(se[i]), int(sh[i]), int(cu[i])) for i in idx)
         print(f"  XCD {x}: {len(idx)} blocks on {len(cus)} CUs (blocks per CU: {sorted(collections.Counter(cus.values()).items())}); duration mean {dur[idx].mean():.1f} max {dur[idx].max():.1f}; last end {end[idx].max():.1f}")
+    # which XCD gets block k: the dispatcher deals consecutive workgroups to consecutive XCDs — a fixed map k % 8 -> XCC_ID?
+    res = collections.Counter((int(a[i, 0]) % 8, int(xcc[i])) for i in range(len(dur)))
+    print("  block index mod 8 -> XCC_ID (count):", sorted(res.items()))
+    # the XCDs finish apart: how much of the makespan is that (sum of a XCD's block durations = its busy time)
+    busy = {x: dur[per_xcc[x]].sum() for x in per_xcc}
+    mean_busy = sum(busy.values()) / len(busy)
+    print("  busy time of each XCD relative to the mean:", {x: round(busy[x] / mean_busy, 4) for x in sorted(busy)},
+          "; last end relative to the mean last end:", {x: round(end[per_xcc[x]].max() / np.mean([end[per_xcc[y]].max() for y in per_xcc]), 4) for x in sorted(per_xcc)})
     # blocks alone on their CU against blocks that shared it
     place = collections.Counter((int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i])) for i in range(len(dur)))
     alone = np.array([place[(int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]))] == 1 for i in range(len(dur))])
