@@ -690,12 +690,12 @@ int nb_launch_accel_sym_f32(nb_ctx* c, const float* x, const float* y, const flo
   // Sinks per lane (set = 256 * KS particles). Equal masses, large n: 12 sinks x 1 source per step (244 VGPRs; fewest accumulator round trips
   // per pair: 159.6 ms at N = 2^20 against 163.7 with 8 sinks x 2 sources, one box); per-particle masses carry two more registers per sink
   // pair: 8 x 2. Smaller n: smaller sets, so that the launch still has enough (set, offset, tile) work items to spread over 256 CUs — measured
-  // (profiles/r03_sym_kernel_development_log.txt, sinks-per-lane sweep): 12 from ~3300 items (n ~ 100 000), 8 from ~700 (n ~ 36 000), else 4.
+  // (profiles/r03_sym_kernel_development_log.txt, sinks-per-lane sweep): 12 from ~3300 items (n ~ 100 000), 8 from ~500 (n ~ 30 000), else 4.
   auto items = [&](int ks, int tj) { const long long ns = (n + BLOCK * ks - 1) / (BLOCK * ks); return ns * ((ns - 1) / 2 + 1) * (BLOCK * ks / tj); };
   const int tj = phi ? 256 : 512;
   int ks = (flags & NB_UNIFORM_MASS) && !phi ? 12 : 8;
   if (ks == 12 && items(12, tj) < 3300) ks = 8;
-  if (ks == 8 && items(8, tj) < 700) ks = 4;
+  if (ks == 8 && items(8, tj) < 500) ks = 4;      // (700 until the blocks of a CU took turns: N = 32 768, 576 items, now runs 6 % faster on 8-sink sets — profiles/r04_sym_ks_sweep_final_kernels.txt)
   if (env_ks == 4 || env_ks == 8 || (env_ks == 12 && (flags & NB_UNIFORM_MASS) && !phi)) ks = (int)env_ks;
 #define NB_RUN(K, UU, PT) run_sym<K, UU, PT>(c, x, y, z, m, n, eps2, G, ax, ay, az, flags, budget, opt.blocks, opt.rounds, (int)opt.turn, phi)
   const int rc = phi ? (ks == 8 ? NB_RUN(8, 1, true) : NB_RUN(4, 2, true))
