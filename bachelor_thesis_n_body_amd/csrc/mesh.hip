@@ -1182,7 +1182,8 @@ int long_range(nb_ctx* c, nb_mesh_state& s, const T* x, const T* y, const T* z, 
   // a mesh of whole bricks: the tiles go to one slot per chunk and a second kernel sums them into the grid (no atomics, no clearing);
   // NB_MESH_STAGE=0 keeps the atomic flush
   static const bool stage_env = !(getenv("NB_MESH_STAGE") && atoi(getenv("NB_MESH_STAGE")) == 0);
-  const bool staged = bricks && stage_env && ngrid % BR == 0;
+  // (and enough particles per brick: the staging buffer holds a 16 KB tile per chunk, every brick has at least one)
+  const bool staged = bricks && stage_env && ngrid % BR == 0 && (int64_t)nb3 * 32 <= n;
   if (staged && s.stage_cap < max_chunks) {
     NB_HIP(c, hipStreamSynchronize(st));
     if (s.stage) { (void)hipFree(s.stage); s.stage = nullptr; s.stage_cap = 0; }

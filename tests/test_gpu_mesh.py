@@ -165,7 +165,7 @@ def test_long_range_through_lds_bricks_matches_oracle(ngrid, interlace, dtype):
     """n >= 1e5 takes the brick-sorted, LDS-privatised deposit and gather: mesh sizes that are not multiples of the 8-cell brick,
     a mesh smaller than one brick tile, particles far outside the box, clustered (one brick holds a third of the particles). Meshes of whole
     bricks (64, 32, 40, 16, and 8 = a single brick that is its own neighbour) take the staged deposit — tiles to one slot per chunk, summed by
-    brick_assemble_kernel — the others the atomic flush."""
+    brick_assemble_kernel — the others (and meshes with fewer than 32 particles per brick) the atomic flush."""
     L, n = 75.0, 120_000
     rng = np.random.default_rng(ngrid)
     pos = rng.uniform(-L, 2 * L, (n, 3))
