@@ -57,7 +57,8 @@ template <bool UNIFORM> __device__ inline float4 ld_src(const float4* p) { retur
 // A block walks its tiles in order; when the sink set changes it stores the set's sink sums to slot (ordinal of this block among the blocks
 // that share the set) of the fp64 `part` slab and loads the next set. A tile cut by a block boundary is walked by two blocks: the one that
 // holds its step 0 writes the tile's source sums to the regular slab slot, the other to its own row of the `bslab`, which is added afterwards
-// (B <= G / HS, so a tile is cut at most once): a set on itself — by the reduce kernel; two different blocks — by a small kernel of its own. All of it is a fixed function of (n, B): bit-reproducible.
+// (B <= G / HS, so a tile is cut at most once): a set on itself — by the reduce kernel; two different blocks — by a small kernel of its own.
+// All of it is a fixed function of (n, B): bit-reproducible.
 __host__ __device__ inline long long part_begin(long long k, long long G, int B) { return k >= B ? G : ((k * G / B) & ~1LL); }
 __host__ __device__ inline int part_block_of(long long s, long long G, int B) {       // the block whose range holds step s
   int k = (int)(s * B / G);
@@ -177,19 +178,20 @@ accel_sym_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, c
   // "priority, then age"): of two co-resident blocks with equal work the first-dispatched runs at 0.75 of the SIMD's issue rate, the other
   // at 0.22, and once the first has ended the second continues alone at the 0.8-0.9 a lone wave reaches (measured with NB_SYM_TRACE at
   // N = 65 536: 462 against 764 us per CU; a lone wave per SIMD over a whole launch: 0.81 / 0.90 of the two-wave rate at N = 65 536 / 2^20) —
-  // the pair finishes 10 % later than two waves sharing fairly would. So the two waves take TURNS at the raised priority: time slices of
-  // 2^turn_shift ticks of the constant-rate counter (100 MHz, the same for every wave of the device), the wave whose slot id has the slice's
+  // the pair finishes 10 % later than two waves sharing fairly would. So the two blocks take TURNS at the raised priority: time slices of
+  // 2^turn_shift ticks of the constant-rate counter (100 MHz, the same for every wave of the device); the block whose turn id has the slice's
   // parity runs at s_setprio 1, the other at 0. The counter is read when a chunk of 8 steps begins and acted on when it ends (scalar work
   // outside the step loop). The slice must be long against that look-up period and short against the launch (the host chooses it:
-  // auto_turn_shift); N = 65 536 with 2^14 ticks = 164 us: per CU 667 against 727 us, launch 819 -> 776 us. First attempts failed for exactly that reason — turns counted in each wave's OWN steps let the leader reach
-  // its next favoured segment first (63 : 37), slices of 10 us looked at every 32 steps (~20-40 us) left the two priorities uncorrelated
-  // (profiles/r04_priority_turns_between_coresident_waves.txt). Pinning the step's LDS reads above its arithmetic does not make a lone wave faster.
-  // The turn is the BLOCK's, not the wave's: all four waves of a block must be favoured in the same slices (they meet at every tile's barrier,
-  // so a block runs at the pace of its slowest wave). The block's id for the turns is the smallest wave-slot id among its waves: where the
-  // CU holds nothing else that is 0 for the first block and 1 for the second on every SIMD; where a third wave sits on one SIMD (bench.py's
-  // clock probe: one sleeping wave per XCD) the per-wave ids there are 1 and 2 against 0 and 1 elsewhere, and per-WAVE turns put one wave of
-  // each block out of phase with its three partners — that CU then straggled by 6 % and, under a deal with few rounds, so did the launch
-  // (bench.py with the probe: +4-8 %; without: -3 % ... 0; profiles/r04_priority_turns_between_coresident_waves.txt).
+  // auto_turn_shift); N = 65 536 with 2^14 ticks = 164 us: per CU 667 against 727 us, launch 819 -> 776 us. First attempts failed for
+  // exactly that reason — turns counted in each wave's OWN steps let the leader reach its next favoured segment first (63 : 37), slices of
+  // 10 us looked at every 32 steps (~20-40 us) left the two priorities uncorrelated (profiles/r04_priority_turns_between_coresident_waves.txt).
+  // Pinning the step's LDS reads above its arithmetic does not make a lone wave faster.
+  // The turn id is the BLOCK's, not the wave's: all four waves of a block must be favoured in the same slices (they meet at every tile's
+  // barrier, so a block runs at the pace of its slowest wave). It is the smallest wave-slot id among the block's waves: where the CU holds
+  // nothing else that is 0 for the first block and 1 for the second on every SIMD; where a third wave sits on one SIMD (bench.py's clock
+  // probe: one sleeping wave per XCD) the per-wave ids there are 1 and 2 against 0 and 1 elsewhere, and per-WAVE turns put one wave of each
+  // block out of phase with its three partners — that CU then straggled by 6 % and, under a deal with few rounds, so did the launch
+  // (bench.py with the probe: +4-8 %; without: -3 % ... 0; same file).
   unsigned slot_id = min(min(turn_slots[0], turn_slots[1]), min(turn_slots[2], turn_slots[3]));
   slot_id = __builtin_amdgcn_readfirstlane(slot_id);
 
@@ -671,7 +673,8 @@ SymOpt sym_options(const nb_ctx* c) {
   static const long long env_mode = env_ll("NB_F32_SYM", 1), env_min_n = env_ll("NB_F32_SYM_MIN_N", 24576),
                          env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_blocks = env_ll("NB_F32_SYM_BLOCKS", 0),
                          env_rounds = env_ll("NB_F32_SYM_ROUNDS", 0), env_ks = env_ll("NB_F32_SYM_KS", 0),
-                         env_turn = env_ll("NB_F32_SYM_TURN_SHIFT", -1);     // priority turns: time slices of 2^shift ticks of the 100 MHz counter; -1 = from the launch (auto_turn_shift), 0 = off
+                         // priority turns: time slices of 2^shift ticks of the 100 MHz counter; -1 = from the launch (auto_turn_shift), 0 = off
+                         env_turn = env_ll("NB_F32_SYM_TURN_SHIFT", -1);
   return SymOpt{c->sym_enable >= 0 ? c->sym_enable : env_mode, c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
                 c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_blocks, env_rounds, env_ks, env_turn};
 }

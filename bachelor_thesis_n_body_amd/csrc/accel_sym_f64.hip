@@ -517,7 +517,8 @@ struct SymOpt { long long mode, min_n, budget, blocks, rounds, ks, turn; };
 SymOpt sym_options(const nb_ctx* c) {
   static const long long env_mode = env_ll("NB_F64_SYM", 1), env_min_n = env_ll("NB_F64_SYM_MIN_N", 16384),
                          env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_blocks = env_ll("NB_F64_SYM_BLOCKS", 0),
-                         env_rounds = env_ll("NB_F64_SYM_ROUNDS", 0), env_ks = env_ll("NB_F64_SYM_KS", 0), env_turn = env_ll("NB_F64_SYM_TURN_SHIFT", -1);    // -1: slice length from the launch (auto_turn_shift), 0: no turns
+                         env_rounds = env_ll("NB_F64_SYM_ROUNDS", 0), env_ks = env_ll("NB_F64_SYM_KS", 0),
+                         env_turn = env_ll("NB_F64_SYM_TURN_SHIFT", -1);    // -1: slice length from the launch (auto_turn_shift), 0: no turns
   return SymOpt{c->sym_enable >= 0 ? c->sym_enable : env_mode, c->sym_min_n >= 0 ? c->sym_min_n : env_min_n,
                 c->sym_slab_bytes >= 0 ? c->sym_slab_bytes : env_budget, env_blocks, env_rounds, env_ks, env_turn};
 }
