@@ -670,7 +670,7 @@ int run_cross(nb_ctx* c, const float* xa, const float* ya, const float* za, cons
 // options of the pair-symmetric kernels: the context's (nb_set_option) or, where unset, the process-wide defaults from the environment
 struct SymOpt { long long mode, min_n, budget, blocks, rounds, ks, turn; };
 SymOpt sym_options(const nb_ctx* c) {
-  static const long long env_mode = env_ll("NB_F32_SYM", 1), env_min_n = env_ll("NB_F32_SYM_MIN_N", 24576),
+  static const long long env_mode = env_ll("NB_F32_SYM", 1), env_min_n = env_ll("NB_F32_SYM_MIN_N", 18432),
                          env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_blocks = env_ll("NB_F32_SYM_BLOCKS", 0),
                          env_rounds = env_ll("NB_F32_SYM_ROUNDS", 0), env_ks = env_ll("NB_F32_SYM_KS", 0),
                          // priority turns: time slices of 2^shift ticks of the 100 MHz counter; -1 = from the launch (auto_turn_shift), 0 = off

@@ -515,7 +515,7 @@ int run_cross(nb_ctx* c, const double* xa, const double* ya, const double* za, c
 // options of the pair-symmetric kernels: the context's (nb_set_option) or, where unset, the process-wide defaults from the environment
 struct SymOpt { long long mode, min_n, budget, blocks, rounds, ks, turn; };
 SymOpt sym_options(const nb_ctx* c) {
-  static const long long env_mode = env_ll("NB_F64_SYM", 1), env_min_n = env_ll("NB_F64_SYM_MIN_N", 16384),
+  static const long long env_mode = env_ll("NB_F64_SYM", 1), env_min_n = env_ll("NB_F64_SYM_MIN_N", 10240),
                          env_budget = env_ll("NB_SYM_SLAB_BYTES", 4ll << 30), env_blocks = env_ll("NB_F64_SYM_BLOCKS", 0),
                          env_rounds = env_ll("NB_F64_SYM_ROUNDS", 0), env_ks = env_ll("NB_F64_SYM_KS", 0),
                          env_turn = env_ll("NB_F64_SYM_TURN_SHIFT", -1);    // -1: slice length from the launch (auto_turn_shift), 0: no turns

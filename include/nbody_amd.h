@@ -130,7 +130,7 @@ int nb_last_run_used_graph(const nb_ctx* ctx);
  * with identical sink and source arrays) evaluate every unordered pair once and give both particles their term (csrc/accel_sym_f32.hip,
  * accel_sym_f64.hip); results agree with the one-sided kernels to rounding (different summation order). Options of a context:
  *   NB_OPT_PAIR_SYMMETRY : 1 = use them where they apply (default; process-wide default from NB_F32_SYM / NB_F64_SYM), 0 = one-sided kernels only
- *   NB_OPT_SYM_MIN_N     : smallest n that takes them (default 24576 fp32 / 16384 fp64: below, the one-sided kernel is faster — profiles/r04_sym_ks_sweep_equal_shares.txt)
+ *   NB_OPT_SYM_MIN_N     : smallest n that takes them (default 18432 fp32 / 10240 fp64: below, the one-sided kernel is faster — profiles/r04_sym_crossover_to_one_sided_bench.txt)
  *   NB_OPT_SYM_SLAB_BYTES: scratch budget for the per-offset partial-sum slabs (default 4 GiB); larger problems run in several passes.
  *                          The budget covers the slabs only: the per-group sink sums (up to ~100 MB at N = 2^20), the fp64 totals of a
  *                          multi-pass launch and 25 % allocation headroom come on top (N = 2^20 fp32: ~3 GB per context in all)

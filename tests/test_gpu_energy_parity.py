@@ -1,7 +1,7 @@
 """The energy kernels AT THE SIZES WHERE THE LARGE-N VARIANTS RUN, directly against the C oracle (oracle/nbody_oracle.c) on the same inputs:
 
   nb_energy       n >= 8192 takes `potential_self_kernel` (csrc/potential.hip: packed self-potential, every unordered pair once),
-  nb_step_energy  n >= 24576 (fp32) / 16384 (fp64) takes the POT variants of the pair-symmetric force kernels (accel_sym_*.hip),
+  nb_step_energy  n >= 18432 (fp32) / 10240 (fp64) takes the POT variants of the pair-symmetric force kernels (accel_sym_*.hip),
   nb_accel_pair_dev with phi: the POT variants of the two-block form,
 
 including eps = 0 with exactly coincident particles (the GUARD instantiations, which drop a pair with a zero denominator — the rule the
@@ -74,7 +74,7 @@ def test_nb_step_energy_matches_oracle_at_large_n(dtype, n, general, coracle):
         K, U = e.step_with_energy(1.0 / 256, 1, 0.01)
         sym = e.last_accel_symmetric()
         st = e.get_state()
-    assert sym == (n >= (24576 if dtype == np.float32 else 16384))
+    assert sym == (n >= (18432 if dtype == np.float32 else 10240))
     p, v, m = _f64(st)
     assert K[0] == pytest.approx(coracle.kinetic(v, m), rel=1e-6 if dtype == np.float32 else 1e-13)
     ref = coracle.potential(p, m, 0.01)
@@ -98,7 +98,7 @@ def test_zero_softening_with_coincident_particles_at_large_n(dtype, general, n, 
         K, U = e.step_with_energy(0.0, 1, 0.0)
         a = e.cached_acc()
         sym = e.last_accel_symmetric()
-    assert sym == (n >= (24576 if dtype == np.float32 else 16384))
+    assert sym == (n >= (18432 if dtype == np.float32 else 10240))
     assert np.isfinite(u) and np.isfinite(U[0]) and np.isfinite(a).all()
     tol = UTOL[dtype]
     note(f"eps=0 nb_energy U n={n} {np.dtype(dtype).name} {'general' if general else 'uniform'}", abs(u / ref - 1), tol)

@@ -98,13 +98,15 @@ def test_step_energy_equals_step_then_energy(dtype, uniform, n, eps):
             k, u = e.energy(eps)
             ks.append(k); us.append(u)
         ref = e.get_state()
-    if dtype == np.float64 and n >= 16384:
-        np.testing.assert_allclose(fused.pos, ref.pos, rtol=1e-13, atol=1e-15)
-        np.testing.assert_allclose(fused.vel, ref.vel, rtol=1e-13, atol=1e-15)
+    if n >= (18432 if dtype == np.float32 else 10240):
+        # pair-symmetric sizes: the POT and the plain variant of the kernel use different tiles (256 / 512 sources), so their sums differ by rounding
+        rt, at = (1e-13, 1e-15) if dtype == np.float64 else (2e-6, 2e-7)
+        np.testing.assert_allclose(fused.pos, ref.pos, rtol=rt, atol=at)
+        np.testing.assert_allclose(fused.vel, ref.vel, rtol=rt, atol=at)
     else:
         np.testing.assert_array_equal(fused.pos, ref.pos)
         np.testing.assert_array_equal(fused.vel, ref.vel)
-    np.testing.assert_allclose(K, ks, rtol=1e-13)
+    np.testing.assert_allclose(K, ks, rtol=1e-9 if (dtype == np.float32 and n >= 18432) else 1e-13)     # (fp32 velocities that differ by rounding: measured 6e-11)
     np.testing.assert_allclose(U, us, rtol=3e-6 if dtype == np.float32 else 1e-12)
 
 

@@ -287,7 +287,7 @@ def test_two_block_entry_matches_oracle(dtype, general, na, nb_, force, coracle)
     acc_b = torch.full((3, nb_), -3.0, dtype=tdt, device="cuda")
     k.accel_pair(A, na, B, nb_, 0.01, 1.3, acc_a, acc_b, False, uniform_mass=not general)
     took_sym = k.last_accel_symmetric()
-    assert took_sym == (min(na, nb_) >= 1 and (bool(force) or 2 * min(na, nb_) >= (24576 if dtype == np.float32 else 16384)))
+    assert took_sym == (min(na, nb_) >= 1 and (bool(force) or 2 * min(na, nb_) >= (18432 if dtype == np.float32 else 10240)))
     first = acc_a.clone()
     k.accel_pair(A, na, B, nb_, 0.01, 1.3, acc_a, acc_b, True, uniform_mass=not general)      # A accumulates, B is overwritten
     torch.cuda.synchronize()

@@ -38,7 +38,7 @@ def test_accel_kdk_equals_separate_launches(dtype, general, n, tail):
     k.accel_kdk(pm, n, pm, n, 0.01, 1.0, acc, False, vel, close, open_, drift, uniform_mass=not general)
     fused_sym = k.last_accel_symmetric()
     k.accel(pm2, n, pm2, n, 0.01, 1.0, acc2, False, uniform_mass=not general)
-    assert k.last_accel_symmetric() == fused_sym == (n >= (24576 if dtype == np.float32 else 16384))
+    assert k.last_accel_symmetric() == fused_sym == (n >= (18432 if dtype == np.float32 else 10240))
     k.kick(vel2, acc2, n, close)
     if open_ != 0.0 or drift != 0.0:
         k.kick(vel2, acc2, n, open_)
